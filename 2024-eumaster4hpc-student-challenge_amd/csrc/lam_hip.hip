@@ -1,0 +1,1087 @@
+// lam_hip.hip -- context, orchestration and the C ABI (include/lam_hip.h) of the MI355X-native
+// dense Conjugate-Gradient hot path.  Kernels: lam_kernels.h.  gfx950 only, no CPU fallback.
+//
+// Orchestration of the loop body of
+//   /root/reference/challenge/main/LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:98-116
+// per shard and iteration k:
+//   gemv_tile_kernel -> [reduce p.Ap across shards] -> update_xr_kernel -> [reduce r.r across
+//   shards] -> update_p_kernel (stores the new p slice into every replica of p) -> [all-gather p]
+// "Across shards" is (a) nothing for one shard, (b) direct peer stores + cross-stream events when
+// one process drives several shards (xGMI point-to-point), (c) RCCL ncclAllReduce / ncclAllGather
+// when there is one process per GPU.  Scalars stay on the device; the host only polls a stop
+// flag with a lag of kLag iterations, so the queue never drains.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/lam_hip.h"
+#include "lam_kernels.h"
+
+using namespace lam;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr int kLag = 4;          // iterations the host may run ahead of the stop flag
+constexpr int kVecBlocksMax = 256;
+
+struct ShardBase {
+    int dev = 0;
+    int index = 0;               // global shard index
+    uint64_t row0 = 0, nrows = 0;
+    hipStream_t stream = nullptr;
+    void *A = nullptr;           // nrows x n
+    void *p = nullptr;           // n (replica)
+    void *Ap = nullptr, *x = nullptr, *r = nullptr, *b = nullptr;  // nrows each
+    void *tmp = nullptr;         // n: scratch vector (gemv op input / residual)
+    double *part_gemv = nullptr; // [gemv_blocks]
+    double *part_vec = nullptr;  // [vec_blocks]
+    double *gather_a = nullptr;  // [kMaxShards] p.Ap partials of all shards (or the reduced scalar at [0])
+    double *gather_b = nullptr;  // [kMaxShards] r.r partials
+    CgScalars *sc = nullptr;     // device scalars
+    CgScalars *sc_host = nullptr;// pinned mirror (filled by an async copy at the end of a call)
+    int *host_flags = nullptr;   // pinned, device-visible: [0] last finished iteration, [1] stop
+    int gemv_blocks = 0, vec_blocks = 0;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_p = nullptr;  // cross-shard ordering
+    hipEvent_t ev_lag[kLag] = {};
+    hipEvent_t ev_g0[kLag] = {}, ev_g1[kLag] = {};              // gemv timing ring
+};
+
+}  // namespace
+
+struct lam_hip_ctx {
+    int dtype = LAM_HIP_F64;
+    int total_shards = 1;          // P
+    int rank = 0, nranks = 1;      // rank mode (one local shard == shard `rank`)
+    bool rank_mode = false;
+    ncclComm_t comm = nullptr;
+    double t_comm_init = 0.0;
+    uint64_t n = 0;
+    bool have_problem = false, have_matrix = false, have_rhs = false, cg_ready = false;
+    int k_done = 0;                // CG iterations enqueued since cg_init
+    std::vector<ShardBase> sh;     // local shards
+    std::string err;
+    // options
+    int64_t opt_gemv_variant = 0;  // 0 = default tile kernel
+    int64_t opt_nt = 1;
+    int64_t opt_generic = 0;       // force the generic kernel
+
+    size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
+    size_t esz_v() const { return dtype == LAM_HIP_F64 ? 8 : 4; }
+};
+
+namespace {
+
+int fail(lam_hip_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), e_ == hipErrorOutOfMemory ? LAM_HIP_ENOMEM : LAM_HIP_EHIP,       \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCLCHK(c, call)                                                                      \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess)                                                                \
+            return fail((c), LAM_HIP_ERCCL, "%s failed: %s (%s:%d)", #call,                   \
+                        ncclGetErrorString(r_), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define LAMCHK(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != 0) return rc_;    \
+    } while (0)
+
+void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
+{
+    // ConjugateGradient_CPU_MPI_OMP.hpp:176-184: n/P rows each, the remainder on the LAST rank
+    const uint64_t base = n / (uint64_t)P;
+    *row0 = base * (uint64_t)q;
+    *nrows = base + ((q == P - 1) ? n % (uint64_t)P : 0);
+}
+
+int vec_grid(uint64_t n_loc)
+{
+    uint64_t b = (n_loc + kBlock - 1) / kBlock;
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(b, kVecBlocksMax));
+}
+
+// ---- typed implementation ----------------------------------------------------------------------
+template <typename TA, typename TV>
+struct Impl {
+    static constexpr int VEC = MatVec<TA>::N;
+    // default GEMV shape: R rows per wave, TILE columns of p in LDS
+    static constexpr int R = 4;
+    static constexpr int TILE = 4096;
+
+    static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic && (c->n % VEC) == 0; }
+
+    static int gemv_grid(const lam_hip_ctx *c, uint64_t nrows)
+    {
+        if (nrows == 0) return 0;
+        const uint64_t rows_per_block = fast_ok(c) ? (uint64_t)kWaves * R : (uint64_t)kWaves;
+        return (int)((nrows + rows_per_block - 1) / rows_per_block);
+    }
+
+    static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
+    {
+        if (s.nrows == 0) return 0;
+        GemvArgs<TA, TV> a;
+        a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
+        a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
+        const int grid = gemv_grid(c, s.nrows);
+        if (fast_ok(c)) {
+            if (c->opt_nt)
+                hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, true, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+            else
+                hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+        } else {
+            hipLaunchKernelGGL((gemv_generic_kernel<TA, TV>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+        }
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+};
+
+template <typename F>
+int dispatch(lam_hip_ctx *c, F &&f)
+{
+    switch (c->dtype) {
+    case LAM_HIP_F64: return f(Impl<double, double>());
+    case LAM_HIP_F32: return f(Impl<float, float>());
+    case LAM_HIP_BF16: return f(Impl<__hip_bfloat16, float>());
+    }
+    return fail(c, LAM_HIP_EINVAL, "bad dtype %d", c->dtype);
+}
+
+int set_dev(lam_hip_ctx *c, const ShardBase &s)
+{
+    HIPCHK(c, hipSetDevice(s.dev));
+    return 0;
+}
+
+PtrList plist_p(lam_hip_ctx *c)
+{
+    PtrList l;
+    l.n = (int)c->sh.size();
+    for (int j = 0; j < l.n; j++) l.p[j] = c->sh[j].p;
+    return l;
+}
+PtrList plist_gather(lam_hip_ctx *c, bool second)
+{
+    PtrList l;
+    l.n = (int)c->sh.size();
+    for (int j = 0; j < l.n; j++) l.p[j] = second ? (void *)c->sh[j].gather_b : (void *)c->sh[j].gather_a;
+    return l;
+}
+
+void free_shard(ShardBase &s)
+{
+    (void)hipSetDevice(s.dev);
+    void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (s.sc_host) (void)hipHostFree(s.sc_host);
+    if (s.host_flags) (void)hipHostFree(s.host_flags);
+    s.host_flags = nullptr;
+    s.A = s.p = s.Ap = s.x = s.r = s.b = s.tmp = nullptr;
+    s.part_gemv = s.part_vec = s.gather_a = s.gather_b = nullptr;
+    s.sc = nullptr; s.sc_host = nullptr;
+}
+
+int create_common(lam_hip_ctx *c)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, LAM_HIP_ENODEV, "no usable HIP device (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    for (auto &s : c->sh) {
+        if (s.dev < 0 || s.dev >= ndev) return fail(nullptr, LAM_HIP_EINVAL, "device id %d out of range (have %d)", s.dev, ndev);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s.dev) != hipSuccess)
+            return fail(nullptr, LAM_HIP_EHIP, "hipGetDeviceProperties(%d) failed", s.dev);
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, LAM_HIP_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", s.dev, prop.gcnArchName);
+        if (hipSetDevice(s.dev) != hipSuccess) return fail(nullptr, LAM_HIP_EHIP, "hipSetDevice(%d) failed", s.dev);
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(nullptr, LAM_HIP_EHIP, "hipStreamCreate failed on device %d", s.dev);
+        hipEvent_t *evs[] = {&s.ev_a, &s.ev_b, &s.ev_p};
+        for (auto ev : evs)
+            if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess)
+                return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
+        for (int i = 0; i < kLag; i++) {
+            if (hipEventCreateWithFlags(&s.ev_lag[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreate(&s.ev_g0[i]) != hipSuccess || hipEventCreate(&s.ev_g1[i]) != hipSuccess)
+                return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
+        }
+    }
+    // peer access between distinct devices of one process (direct xGMI stores)
+    for (auto &s : c->sh)
+        for (auto &t : c->sh)
+            if (s.dev != t.dev) {
+                int can = 0;
+                (void)hipSetDevice(s.dev);
+                if (hipDeviceCanAccessPeer(&can, s.dev, t.dev) != hipSuccess || !can)
+                    return fail(nullptr, LAM_HIP_EHIP, "device %d cannot access peer %d", s.dev, t.dev);
+                hipError_t pe = hipDeviceEnablePeerAccess(t.dev, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(nullptr, LAM_HIP_EHIP, "hipDeviceEnablePeerAccess(%d->%d): %s", s.dev, t.dev, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+    return 0;
+}
+
+int sync_all(lam_hip_ctx *c)
+{
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+    }
+    return 0;
+}
+
+// Reduce the per-workgroup partials in `part` (n_part values) of every local shard into the
+// array the next kernel sums.  Returns through (*red, *nred) what that kernel must read.
+//   1 shard            : the partials themselves
+//   several, 1 process : finalize -> slot q of every shard's gather array (peer stores) + events
+//   rank mode          : finalize -> gather[0], ncclAllReduce in place
+int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop)
+{
+    const int L = (int)c->sh.size();
+    if (c->total_shards == 1) return 0;
+    if (c->rank_mode) {
+        ShardBase &s = c->sh[0];
+        PtrList dst; dst.n = 1; dst.p[0] = second ? s.gather_b : s.gather_a;
+        const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
+        const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
+        hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, dst, 0,
+                           check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        double *buf = second ? s.gather_b : s.gather_a;
+        NCCLCHK(c, ncclAllReduce(buf, buf, 1, ncclDouble, ncclSum, c->comm, s.stream));
+        return 0;
+    }
+    PtrList dst = plist_gather(c, second);
+    for (int q = 0; q < L; q++) {
+        ShardBase &s = c->sh[q];
+        LAMCHK(set_dev(c, s));
+        const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
+        const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
+        hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, dst, s.index,
+                           check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(second ? s.ev_b : s.ev_a, s.stream));
+    }
+    for (int q = 0; q < L; q++) {
+        ShardBase &s = c->sh[q];
+        LAMCHK(set_dev(c, s));
+        for (int t = 0; t < L; t++)
+            if (t != q) HIPCHK(c, hipStreamWaitEvent(s.stream, second ? c->sh[t].ev_b : c->sh[t].ev_a, 0));
+    }
+    return 0;
+}
+
+void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, const double **red, int *nred)
+{
+    if (c->total_shards == 1) {
+        *red = use_gemv_part ? s.part_gemv : s.part_vec;
+        *nred = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
+    } else if (c->rank_mode) {
+        *red = second ? s.gather_b : s.gather_a;
+        *nred = 1;
+    } else {
+        *red = second ? s.gather_b : s.gather_a;
+        *nred = c->total_shards;
+    }
+}
+
+// make every replica of p complete after the slices were stored
+int gather_p_step(lam_hip_ctx *c)
+{
+    const int L = (int)c->sh.size();
+    if (c->total_shards == 1) return 0;
+    if (c->rank_mode) {
+        ShardBase &s = c->sh[0];
+        const uint64_t base = c->n / (uint64_t)c->nranks;
+        const size_t ev = c->esz_v();
+        const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+        if (c->n % (uint64_t)c->nranks == 0) {
+            NCCLCHK(c, ncclAllGather((const char *)s.p + s.row0 * ev, s.p, base, dt, c->comm, s.stream));
+        } else {
+            // uneven last block (reference: MPI_Allgatherv): one broadcast per owner
+            NCCLCHK(c, ncclGroupStart());
+            for (int q = 0; q < c->nranks; q++) {
+                uint64_t r0, nr;
+                partition(c->n, c->nranks, q, &r0, &nr);
+                char *ptr = (char *)s.p + r0 * ev;
+                NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+            }
+            NCCLCHK(c, ncclGroupEnd());
+        }
+        return 0;
+    }
+    for (int q = 0; q < L; q++) {
+        ShardBase &s = c->sh[q];
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipEventRecord(s.ev_p, s.stream));
+    }
+    for (int q = 0; q < L; q++) {
+        ShardBase &s = c->sh[q];
+        LAMCHK(set_dev(c, s));
+        for (int t = 0; t < L; t++)
+            if (t != q) HIPCHK(c, hipStreamWaitEvent(s.stream, c->sh[t].ev_p, 0));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// The typed bodies below are written as generic lambdas over Impl<TA,TV>; TV is recovered with
+// this small trait.
+namespace {
+template <typename T> struct ImplTraits;
+template <typename TA_, typename TV_> struct ImplTraits<Impl<TA_, TV_>> { using TA = TA_; using TV = TV_; };
+
+int do_cg_init(lam_hip_ctx *c)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        PtrList pl = plist_p(c);
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            hipLaunchKernelGGL((cg_init_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b,
+                               (TV *)s.x, (TV *)s.r, pl, s.row0, s.nrows, s.part_vec);
+            HIPCHK(c, hipGetLastError());
+        }
+        LAMCHK(reduce_step(c, /*second=*/true, /*gemv_part=*/false, /*check_stop=*/false));
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            const double *red; int nred;
+            red_source(c, s, true, false, &red, &nred);
+            hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(kBlock), 0, s.stream, red, nred, s.sc);
+            HIPCHK(c, hipGetLastError());
+        }
+        LAMCHK(gather_p_step(c));
+        c->k_done = 0;
+        c->cg_ready = true;
+        return 0;
+    });
+}
+
+int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TV = typename ImplTraits<I>::TV;
+        // 1. GEMV + partial p.Ap
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+            HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+        }
+        LAMCHK(reduce_step(c, false, true, true));
+        // 2. x, r update + partial r.r
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            const double *red; int nred;
+            red_source(c, s, false, true, &red, &nred);
+            hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
+                               (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec);
+            HIPCHK(c, hipGetLastError());
+        }
+        LAMCHK(reduce_step(c, true, false, true));
+        // 3. stop test + p update (into every replica)
+        PtrList pl = plist_p(c);
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            const double *red; int nred;
+            red_source(c, s, true, false, &red, &nred);
+            hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
+                               rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows,
+                               (volatile int *)s.host_flags);
+            HIPCHK(c, hipGetLastError());
+        }
+        LAMCHK(gather_p_step(c));
+        return 0;
+    });
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int lam_hip_abi_version(void) { return LAM_HIP_ABI_VERSION; }
+
+int lam_hip_device_count(int *count)
+{
+    if (!count) return LAM_HIP_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, LAM_HIP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return 0;
+}
+
+const char *lam_hip_last_error(const lam_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device_ids)
+{
+    if (!out) return LAM_HIP_EINVAL;
+    *out = nullptr;
+    if (dtype < LAM_HIP_F64 || dtype > LAM_HIP_BF16) return fail(nullptr, LAM_HIP_EINVAL, "bad dtype %d", dtype);
+    if (n_shards < 1 || n_shards > kMaxShards) return fail(nullptr, LAM_HIP_EINVAL, "n_shards must be 1..%d", kMaxShards);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LAM_HIP_ENODEV, "no usable HIP device; this library has no CPU path");
+    std::unique_ptr<lam_hip_ctx> c(new lam_hip_ctx);
+    c->dtype = dtype;
+    c->total_shards = n_shards;
+    c->sh.resize(n_shards);
+    for (int q = 0; q < n_shards; q++) {
+        c->sh[q].index = q;
+        c->sh[q].dev = device_ids ? device_ids[q] : q % ndev;
+    }
+    int rc = create_common(c.get());
+    if (rc != 0) { for (auto &s : c->sh) free_shard(s); return rc; }
+    *out = c.release();
+    return 0;
+}
+
+int lam_hip_get_unique_id(void *unique_id_out)
+{
+    if (!unique_id_out) return LAM_HIP_EINVAL;
+    static_assert(sizeof(ncclUniqueId) == LAM_HIP_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, LAM_HIP_ERCCL, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(unique_id_out, &id, sizeof id);
+    return 0;
+}
+
+int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, int nranks, const void *unique_id)
+{
+    if (!out) return LAM_HIP_EINVAL;
+    *out = nullptr;
+    if (dtype < LAM_HIP_F64 || dtype > LAM_HIP_BF16) return fail(nullptr, LAM_HIP_EINVAL, "bad dtype %d", dtype);
+    if (nranks < 1 || nranks > kMaxShards || rank < 0 || rank >= nranks)
+        return fail(nullptr, LAM_HIP_EINVAL, "bad rank %d / nranks %d", rank, nranks);
+    if (nranks > 1 && !unique_id) return fail(nullptr, LAM_HIP_EINVAL, "unique_id required when nranks > 1");
+    std::unique_ptr<lam_hip_ctx> c(new lam_hip_ctx);
+    c->dtype = dtype;
+    c->total_shards = nranks;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->rank_mode = nranks > 1;
+    c->sh.resize(1);
+    c->sh[0].index = rank;
+    c->sh[0].dev = device_id;
+    int rc = create_common(c.get());
+    if (rc != 0) { for (auto &s : c->sh) free_shard(s); return rc; }
+    if (nranks > 1) {
+        const double t0 = now_s();
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof id);
+        (void)hipSetDevice(device_id);
+        ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+        if (r != ncclSuccess) {
+            for (auto &s : c->sh) free_shard(s);
+            return fail(nullptr, LAM_HIP_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));
+        }
+        c->t_comm_init = now_s() - t0;
+    }
+    *out = c.release();
+    return 0;
+}
+
+void lam_hip_destroy(lam_hip_ctx *c)
+{
+    if (!c) return;
+    for (auto &s : c->sh) {
+        (void)hipSetDevice(s.dev);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+    }
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    for (auto &s : c->sh) {
+        free_shard(s);
+        hipEvent_t evs[] = {s.ev_a, s.ev_b, s.ev_p};
+        for (auto e : evs) if (e) (void)hipEventDestroy(e);
+        for (int i = 0; i < kLag; i++) {
+            if (s.ev_lag[i]) (void)hipEventDestroy(s.ev_lag[i]);
+            if (s.ev_g0[i]) (void)hipEventDestroy(s.ev_g0[i]);
+            if (s.ev_g1[i]) (void)hipEventDestroy(s.ev_g1[i]);
+        }
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete c;
+}
+
+int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (n == 0) return fail(c, LAM_HIP_EINVAL, "n must be > 0");
+    if (n < (uint64_t)c->total_shards) return fail(c, LAM_HIP_EINVAL, "n (%llu) smaller than the number of shards", (unsigned long long)n);
+    c->n = n;
+    c->have_problem = c->have_matrix = c->have_rhs = c->cg_ready = false;
+    const size_t ea = c->esz_a(), ev = c->esz_v();
+    for (auto &s : c->sh) {
+        free_shard(s);
+        partition(n, c->total_shards, s.index, &s.row0, &s.nrows);
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipMalloc(&s.A, std::max<size_t>(16, s.nrows * n * ea)));
+        HIPCHK(c, hipMalloc(&s.p, n * ev + 16));
+        HIPCHK(c, hipMalloc(&s.tmp, n * ev + 16));
+        void **vecs[] = {&s.Ap, &s.x, &s.r, &s.b};
+        for (auto v : vecs) HIPCHK(c, hipMalloc(v, s.nrows * ev + 16));
+        s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
+        // worst case over kernel variants (generic kernel: 4 rows per workgroup)
+        const int gemv_blocks_max = (int)((s.nrows + kWaves - 1) / kWaves) + 1;
+        s.vec_blocks = vec_grid(s.nrows);
+        HIPCHK(c, hipMalloc((void **)&s.part_gemv, sizeof(double) * (size_t)gemv_blocks_max));
+        HIPCHK(c, hipMalloc((void **)&s.part_vec, sizeof(double) * kVecBlocksMax));
+        HIPCHK(c, hipMalloc((void **)&s.gather_a, sizeof(double) * kMaxShards));
+        HIPCHK(c, hipMalloc((void **)&s.gather_b, sizeof(double) * kMaxShards));
+        HIPCHK(c, hipMalloc((void **)&s.sc, sizeof(CgScalars)));
+        HIPCHK(c, hipHostMalloc((void **)&s.sc_host, sizeof(CgScalars), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&s.host_flags, 64, hipHostMallocDefault));
+        s.host_flags[0] = s.host_flags[1] = 0;
+        HIPCHK(c, hipMemsetAsync(s.sc, 0, sizeof(CgScalars), s.stream));
+        HIPCHK(c, hipMemsetAsync(s.gather_a, 0, sizeof(double) * kMaxShards, s.stream));
+        HIPCHK(c, hipMemsetAsync(s.gather_b, 0, sizeof(double) * kMaxShards, s.stream));
+        HIPCHK(c, hipMemsetAsync(s.p, 0, n * ev, s.stream));
+        memset(s.sc_host, 0, sizeof(CgScalars));
+    }
+    LAMCHK(sync_all(c));
+    c->have_problem = true;
+    return 0;
+}
+
+int lam_hip_n(const lam_hip_ctx *c, uint64_t *n)
+{
+    if (!c || !n) return LAM_HIP_EINVAL;
+    *n = c->n;
+    return 0;
+}
+
+int lam_hip_num_shards(const lam_hip_ctx *c, int *total, int *local)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (total) *total = c->total_shards;
+    if (local) *local = (int)c->sh.size();
+    return 0;
+}
+
+int lam_hip_get_partition(const lam_hip_ctx *c, int shard, uint64_t *row0, uint64_t *nrows)
+{
+    if (!c || !row0 || !nrows || shard < 0 || shard >= c->total_shards || !c->have_problem) return LAM_HIP_EINVAL;
+    partition(c->n, c->total_shards, shard, row0, nrows);
+    return 0;
+}
+
+static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, bool upload)
+{
+    if (!c || (!host && nrows)) return LAM_HIP_EINVAL;
+    if (!c->have_problem) return fail(c, LAM_HIP_ESTATE, "call lam_hip_set_problem first");
+    if (row0 + nrows > c->n) return fail(c, LAM_HIP_EINVAL, "rows [%llu,+%llu) outside the matrix", (unsigned long long)row0, (unsigned long long)nrows);
+    const size_t ea = c->esz_a();
+    const size_t eh = c->dtype == LAM_HIP_BF16 ? 4 : ea;   // host element size (bf16 travels as float)
+    uint64_t covered = 0;
+    for (auto &s : c->sh) {
+        const uint64_t lo = std::max(row0, s.row0), hi = std::min(row0 + nrows, s.row0 + s.nrows);
+        if (lo >= hi) continue;
+        LAMCHK(set_dev(c, s));
+        const uint64_t cnt = (hi - lo) * c->n;
+        char *hptr = (char *)host + (lo - row0) * c->n * eh;
+        char *dptr = (char *)s.A + (lo - s.row0) * c->n * ea;
+        if (c->dtype == LAM_HIP_BF16) {
+            // stage through a device float buffer in chunks of rows
+            const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / (c->n * 4));
+            float *stage = nullptr;
+            HIPCHK(c, hipMalloc((void **)&stage, chunk_rows * c->n * 4));
+            for (uint64_t r = lo; r < hi; r += chunk_rows) {
+                const uint64_t nr = std::min(chunk_rows, hi - r), ne = nr * c->n;
+                char *hp = (char *)host + (r - row0) * c->n * 4;
+                __hip_bfloat16 *dp = (__hip_bfloat16 *)s.A + (r - s.row0) * c->n;
+                if (upload) {
+                    HIPCHK(c, hipMemcpyAsync(stage, hp, ne * 4, hipMemcpyHostToDevice, s.stream));
+                    hipLaunchKernelGGL((f32_to_bf16_kernel<float>), dim3(1024), dim3(kBlock), 0, s.stream, stage, dp, ne);
+                    HIPCHK(c, hipGetLastError());
+                    HIPCHK(c, hipStreamSynchronize(s.stream));
+                } else {
+                    std::vector<unsigned short> tmp(ne);
+                    HIPCHK(c, hipMemcpyAsync(tmp.data(), dp, ne * 2, hipMemcpyDeviceToHost, s.stream));
+                    HIPCHK(c, hipStreamSynchronize(s.stream));
+                    float *fp = (float *)hp;
+                    for (uint64_t i = 0; i < ne; i++) { unsigned u = ((unsigned)tmp[i]) << 16; memcpy(&fp[i], &u, 4); }
+                }
+            }
+            HIPCHK(c, hipFree(stage));
+        } else {
+            // chunked so that a single call never exceeds 2^31 elements (the reference's int-count trap)
+            const uint64_t chunk = 1ull << 28;
+            for (uint64_t off = 0; off < cnt; off += chunk) {
+                const uint64_t ne = std::min(chunk, cnt - off);
+                if (upload) HIPCHK(c, hipMemcpyAsync(dptr + off * ea, hptr + off * ea, ne * ea, hipMemcpyHostToDevice, s.stream));
+                else HIPCHK(c, hipMemcpyAsync(hptr + off * ea, dptr + off * ea, ne * ea, hipMemcpyDeviceToHost, s.stream));
+            }
+            HIPCHK(c, hipStreamSynchronize(s.stream));
+        }
+        covered += hi - lo;
+    }
+    if (covered != nrows)
+        return fail(c, LAM_HIP_EINVAL, "rows [%llu,+%llu) are not all owned by this process", (unsigned long long)row0, (unsigned long long)nrows);
+    if (upload) { c->have_matrix = true; c->cg_ready = false; }
+    return 0;
+}
+
+int lam_hip_upload_rows(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, const void *host_rows)
+{
+    return rows_xfer(c, row0, nrows, const_cast<void *>(host_rows), true);
+}
+int lam_hip_download_rows(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host_rows)
+{
+    return rows_xfer(c, row0, nrows, host_rows, false);
+}
+
+int lam_hip_generate_tridiag(lam_hip_ctx *c)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (!c->have_problem) return fail(c, LAM_HIP_ESTATE, "call lam_hip_set_problem first");
+    LAMCHK(dispatch(c, [&](auto impl) -> int {
+        using TA = typename ImplTraits<decltype(impl)>::TA;
+        for (auto &s : c->sh) {
+            if (s.nrows == 0) continue;
+            LAMCHK(set_dev(c, s));
+            hipLaunchKernelGGL((gen_tridiag_kernel<TA>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, c->n);
+            HIPCHK(c, hipGetLastError());
+        }
+        return 0;
+    }));
+    LAMCHK(sync_all(c));
+    c->have_matrix = true; c->cg_ready = false;
+    return 0;
+}
+
+int lam_hip_generate_random_spd(lam_hip_ctx *c, uint64_t seed, double cond)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (!c->have_problem) return fail(c, LAM_HIP_ESTATE, "call lam_hip_set_problem first");
+    if (!(cond >= 1.0)) return fail(c, LAM_HIP_EINVAL, "cond must be >= 1");
+    LAMCHK(dispatch(c, [&](auto impl) -> int {
+        using TA = typename ImplTraits<decltype(impl)>::TA;
+        for (auto &s : c->sh) {
+            if (s.nrows == 0) continue;
+            LAMCHK(set_dev(c, s));
+            hipLaunchKernelGGL((gen_random_spd_kernel<TA>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, c->n, seed, cond);
+            HIPCHK(c, hipGetLastError());
+        }
+        return 0;
+    }));
+    LAMCHK(sync_all(c));
+    c->have_matrix = true; c->cg_ready = false;
+    return 0;
+}
+
+int lam_hip_set_rhs(lam_hip_ctx *c, const void *b_host)
+{
+    if (!c || !b_host) return LAM_HIP_EINVAL;
+    if (!c->have_problem) return fail(c, LAM_HIP_ESTATE, "call lam_hip_set_problem first");
+    const size_t ev = c->esz_v();
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipMemcpyAsync(s.b, (const char *)b_host + s.row0 * ev, s.nrows * ev, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+    }
+    c->have_rhs = true; c->cg_ready = false;
+    return 0;
+}
+
+static int gen_rhs(lam_hip_ctx *c, int random, uint64_t seed, double value)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (!c->have_problem) return fail(c, LAM_HIP_ESTATE, "call lam_hip_set_problem first");
+    LAMCHK(dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            hipLaunchKernelGGL((gen_rhs_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (TV *)s.b, s.row0, s.nrows, random, seed, value);
+            HIPCHK(c, hipGetLastError());
+        }
+        return 0;
+    }));
+    LAMCHK(sync_all(c));
+    c->have_rhs = true; c->cg_ready = false;
+    return 0;
+}
+int lam_hip_generate_rhs(lam_hip_ctx *c, double value) { return gen_rhs(c, 0, 0, value); }
+int lam_hip_generate_random_rhs(lam_hip_ctx *c, uint64_t seed) { return gen_rhs(c, 1, seed, 0.0); }
+
+int lam_hip_cg_init(lam_hip_ctx *c)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (!c->have_matrix || !c->have_rhs) return fail(c, LAM_HIP_ESTATE, "matrix and rhs must be set before cg_init");
+    LAMCHK(do_cg_init(c));
+    LAMCHK(sync_all(c));
+    for (auto &s : c->sh) s.host_flags[0] = s.host_flags[1] = 0;
+    return 0;
+}
+
+int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stats *st)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (!c->cg_ready) return fail(c, LAM_HIP_ESTATE, "call lam_hip_cg_init first");
+    if (iters < 0) return fail(c, LAM_HIP_EINVAL, "iters must be >= 0");
+    const double t0 = now_s();
+    ShardBase &s0 = c->sh[0];
+    double gemv_ms = 0.0;
+    int gemv_samples = 0;
+    int enq = 0;
+    bool stopped = false;
+    // already converged in an earlier call?
+    LAMCHK(set_dev(c, s0));
+    HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
+    HIPCHK(c, hipStreamSynchronize(s0.stream));
+    stopped = s0.sc_host->stop != 0;
+    const int k_first = c->k_done + 1;
+    for (int i = 0; i < iters && !stopped; i++) {
+        const int k = k_first + i;
+        const int slot = i % kLag;
+        if (i >= kLag) {
+            // the iteration enqueued kLag steps ago is done: harvest its GEMV time and stop flag
+            LAMCHK(set_dev(c, s0));
+            HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) == hipSuccess) { gemv_ms += ms; gemv_samples++; }
+            if (((volatile int *)s0.host_flags)[1]) { stopped = true; break; }
+        }
+        LAMCHK(enqueue_iteration(c, k, rel_error, slot));
+        LAMCHK(set_dev(c, s0));
+        // update_p_kernel stores the stop flag straight into pinned host memory; mark the iteration
+        HIPCHK(c, hipEventRecord(s0.ev_lag[slot], s0.stream));
+        enq++;
+    }
+    LAMCHK(sync_all(c));
+    // harvest the GEMV timings still in the ring
+    for (int j = std::max(0, enq - kLag); j < enq; j++) {
+        float ms = 0.f;
+        const int slot = j % kLag;
+        if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) == hipSuccess) { gemv_ms += ms; gemv_samples++; }
+    }
+    LAMCHK(set_dev(c, s0));
+    HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
+    HIPCHK(c, hipStreamSynchronize(s0.stream));
+    const CgScalars sc = *s0.sc_host;
+    c->k_done = sc.iters;  // iterations after a stop were no-ops
+    const double t1 = now_s();
+    if (st) {
+        memset(st, 0, sizeof *st);
+        const int ran = sc.iters - (k_first - 1);
+        st->converged = sc.stop != 0;
+        // reference loop counter on exit: the converging iteration, else (last iteration)+1
+        st->num_iters = sc.stop ? sc.iters : sc.iters + 1;
+        st->rel_err = std::sqrt(sc.rr[sc.iters & 1] / sc.bb);
+        st->t_total = t1 - t0;
+        st->t_iter = ran > 0 ? (t1 - t0) / ran : 0.0;
+        st->t_gemv = gemv_samples > 0 ? gemv_ms * 1e-3 / gemv_samples : 0.0;
+        st->t_comm_init = c->t_comm_init;
+        st->gemv_bytes = (double)c->esz_a() * (double)s0.nrows * (double)c->n + (double)c->esz_v() * (double)(c->n + s0.nrows);
+    }
+    return 0;
+}
+
+int lam_hip_solve(lam_hip_ctx *c, int max_iters, double rel_error, lam_hip_stats *st)
+{
+    if (!c) return LAM_HIP_EINVAL;
+    if (max_iters < 0) return fail(c, LAM_HIP_EINVAL, "max_iters must be >= 0");
+    const double t0 = now_s();
+    LAMCHK(lam_hip_cg_init(c));
+    LAMCHK(lam_hip_cg_iterate(c, max_iters, rel_error, st));
+    if (st) st->t_total = now_s() - t0;
+    return 0;
+}
+
+// all-gather a per-shard slice vector (x) into a full host vector
+int lam_hip_get_solution(lam_hip_ctx *c, void *x_host)
+{
+    if (!c || !x_host) return LAM_HIP_EINVAL;
+    if (!c->cg_ready) return fail(c, LAM_HIP_ESTATE, "no solution yet");
+    const size_t ev = c->esz_v();
+    if (c->rank_mode) {
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+        HIPCHK(c, hipMemcpyAsync((char *)s.tmp + s.row0 * ev, s.x, s.nrows * ev, hipMemcpyDeviceToDevice, s.stream));
+        NCCLCHK(c, ncclGroupStart());
+        for (int q = 0; q < c->nranks; q++) {
+            uint64_t r0, nr;
+            partition(c->n, c->nranks, q, &r0, &nr);
+            char *ptr = (char *)s.tmp + r0 * ev;
+            NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+        }
+        NCCLCHK(c, ncclGroupEnd());
+        HIPCHK(c, hipMemcpyAsync(x_host, s.tmp, c->n * ev, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+        return 0;
+    }
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipMemcpyAsync((char *)x_host + s.row0 * ev, s.x, s.nrows * ev, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+    }
+    return 0;
+}
+
+// y = A v for a full-length DEVICE-replicated vector held in every shard's tmp; result slices in Ap
+static int gemv_tmp(lam_hip_ctx *c)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TV = typename ImplTraits<I>::TV;
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.tmp, (TV *)s.Ap, nullptr, nullptr));
+        }
+        return 0;
+    });
+}
+
+int lam_hip_gemv(lam_hip_ctx *c, const void *x_host, void *y_host)
+{
+    if (!c || !x_host || !y_host) return LAM_HIP_EINVAL;
+    if (!c->have_matrix) return fail(c, LAM_HIP_ESTATE, "matrix not set");
+    const size_t ev = c->esz_v();
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipMemcpyAsync(s.tmp, x_host, c->n * ev, hipMemcpyHostToDevice, s.stream));
+    }
+    LAMCHK(gemv_tmp(c));
+    c->cg_ready = false;  // Ap was overwritten
+    if (c->rank_mode) {
+        ShardBase &s = c->sh[0];
+        const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+        HIPCHK(c, hipMemcpyAsync((char *)s.tmp + s.row0 * ev, s.Ap, s.nrows * ev, hipMemcpyDeviceToDevice, s.stream));
+        NCCLCHK(c, ncclGroupStart());
+        for (int q = 0; q < c->nranks; q++) {
+            uint64_t r0, nr;
+            partition(c->n, c->nranks, q, &r0, &nr);
+            char *ptr = (char *)s.tmp + r0 * ev;
+            NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+        }
+        NCCLCHK(c, ncclGroupEnd());
+        HIPCHK(c, hipMemcpyAsync(y_host, s.tmp, c->n * ev, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+        return 0;
+    }
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipMemcpyAsync((char *)y_host + s.row0 * ev, s.Ap, s.nrows * ev, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+    }
+    return 0;
+}
+
+int lam_hip_gemv_only(lam_hip_ctx *c, int reps, double *sec)
+{
+    if (!c || !sec || reps < 1) return LAM_HIP_EINVAL;
+    if (!c->have_matrix) return fail(c, LAM_HIP_ESTATE, "matrix not set");
+    c->cg_ready = false;
+    double worst = 0.0;
+    LAMCHK(dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TV = typename ImplTraits<I>::TV;
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr));  // warm-up
+            HIPCHK(c, hipEventRecord(s.ev_g0[0], s.stream));
+            for (int i = 0; i < reps; i++) LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr));
+            HIPCHK(c, hipEventRecord(s.ev_g1[0], s.stream));
+        }
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            HIPCHK(c, hipEventSynchronize(s.ev_g1[0]));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, s.ev_g0[0], s.ev_g1[0]));
+            worst = std::max(worst, (double)ms * 1e-3 / reps);
+        }
+        return 0;
+    }));
+    *sec = worst;
+    return 0;
+}
+
+int lam_hip_true_residual(lam_hip_ctx *c, double *rel_res)
+{
+    if (!c || !rel_res) return LAM_HIP_EINVAL;
+    if (!c->cg_ready) return fail(c, LAM_HIP_ESTATE, "no solution yet");
+    const size_t ev = c->esz_v();
+    // replicate x into every shard's tmp
+    if (c->rank_mode) {
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+        HIPCHK(c, hipMemcpyAsync((char *)s.tmp + s.row0 * ev, s.x, s.nrows * ev, hipMemcpyDeviceToDevice, s.stream));
+        NCCLCHK(c, ncclGroupStart());
+        for (int q = 0; q < c->nranks; q++) {
+            uint64_t r0, nr;
+            partition(c->n, c->nranks, q, &r0, &nr);
+            char *ptr = (char *)s.tmp + r0 * ev;
+            NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+        }
+        NCCLCHK(c, ncclGroupEnd());
+    } else {
+        LAMCHK(sync_all(c));
+        for (auto &dst : c->sh)
+            for (auto &src : c->sh) {
+                LAMCHK(set_dev(c, dst));
+                HIPCHK(c, hipMemcpyAsync((char *)dst.tmp + src.row0 * ev, src.x, src.nrows * ev, hipMemcpyDefault, dst.stream));
+            }
+        LAMCHK(sync_all(c));
+    }
+    // Ap is reused as scratch for A x: CG state stays valid because every iteration rewrites Ap first
+    LAMCHK(gemv_tmp(c));
+    double num = 0.0, den = 0.0;
+    LAMCHK(dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            std::vector<double> h(2 * kVecBlocksMax);
+            hipLaunchKernelGGL((resid_partial_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b, (const TV *)s.Ap, s.nrows, s.part_vec);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(h.data(), s.part_vec, sizeof(double) * s.vec_blocks, hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(c, hipStreamSynchronize(s.stream));
+            for (int i = 0; i < s.vec_blocks; i++) num += h[i];
+            hipLaunchKernelGGL((dot_partial_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b, (const TV *)s.b, s.nrows, s.part_vec);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(h.data(), s.part_vec, sizeof(double) * s.vec_blocks, hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(c, hipStreamSynchronize(s.stream));
+            for (int i = 0; i < s.vec_blocks; i++) den += h[i];
+        }
+        return 0;
+    }));
+    if (c->rank_mode) {
+        ShardBase &s = c->sh[0];
+        double hv[2] = {num, den};
+        HIPCHK(c, hipMemcpyAsync(s.gather_a, hv, sizeof hv, hipMemcpyHostToDevice, s.stream));
+        NCCLCHK(c, ncclAllReduce(s.gather_a, s.gather_a, 2, ncclDouble, ncclSum, c->comm, s.stream));
+        HIPCHK(c, hipMemcpyAsync(hv, s.gather_a, sizeof hv, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+        num = hv[0]; den = hv[1];
+    }
+    *rel_res = std::sqrt(num / den);
+    return 0;
+}
+
+int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t n, double *result)
+{
+    if (!c || !x_host || !y_host || !result) return LAM_HIP_EINVAL;
+    ShardBase &s = c->sh[0];
+    LAMCHK(set_dev(c, s));
+    const size_t ev = c->esz_v();
+    void *dx = nullptr, *dy = nullptr;
+    double *part = nullptr;
+    HIPCHK(c, hipMalloc(&dx, n * ev + 16));
+    HIPCHK(c, hipMalloc(&dy, n * ev + 16));
+    HIPCHK(c, hipMalloc((void **)&part, sizeof(double) * kVecBlocksMax));
+    HIPCHK(c, hipMemcpyAsync(dx, x_host, n * ev, hipMemcpyHostToDevice, s.stream));
+    HIPCHK(c, hipMemcpyAsync(dy, y_host, n * ev, hipMemcpyHostToDevice, s.stream));
+    const int grid = vec_grid(n);
+    int rc = dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        hipLaunchKernelGGL((dot_partial_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const TV *)dx, (const TV *)dy, n, part);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    });
+    if (rc == 0) {
+        std::vector<double> h(grid);
+        hipError_t e = hipMemcpyAsync(h.data(), part, sizeof(double) * grid, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess) rc = fail(c, LAM_HIP_EHIP, "dot readback: %s", hipGetErrorString(e));
+        double t = 0.0;
+        for (int i = 0; i < grid; i++) t += h[i];   // same fixed order as block_sum_array for grid <= 256
+        *result = t;
+    }
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(part);
+    return rc;
+}
+
+int lam_hip_axpby(lam_hip_ctx *c, double alpha, const void *x_host, double beta, void *y_host, uint64_t n)
+{
+    if (!c || !x_host || !y_host) return LAM_HIP_EINVAL;
+    ShardBase &s = c->sh[0];
+    LAMCHK(set_dev(c, s));
+    const size_t ev = c->esz_v();
+    void *dx = nullptr, *dy = nullptr;
+    HIPCHK(c, hipMalloc(&dx, n * ev + 16));
+    HIPCHK(c, hipMalloc(&dy, n * ev + 16));
+    HIPCHK(c, hipMemcpyAsync(dx, x_host, n * ev, hipMemcpyHostToDevice, s.stream));
+    HIPCHK(c, hipMemcpyAsync(dy, y_host, n * ev, hipMemcpyHostToDevice, s.stream));
+    int rc = dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        hipLaunchKernelGGL((axpby_kernel<TV>), dim3(vec_grid(n)), dim3(kBlock), 0, s.stream, (TV)alpha, (const TV *)dx, (TV)beta, (TV *)dy, n);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    });
+    if (rc == 0) {
+        hipError_t e = hipMemcpyAsync(y_host, dy, n * ev, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+        if (e != hipSuccess) rc = fail(c, LAM_HIP_EHIP, "axpby readback: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dx); (void)hipFree(dy);
+    return rc;
+}
+
+int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return LAM_HIP_EINVAL;
+    if (!strcmp(name, "gemv_variant")) c->opt_gemv_variant = value;
+    else if (!strcmp(name, "nt_loads")) c->opt_nt = value;
+    else if (!strcmp(name, "force_generic")) {
+        c->opt_generic = value;
+        for (auto &s : c->sh)
+            if (c->have_problem) s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
+    } else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
+    return 0;
+}
+
+int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
+{
+    if (!c || !name || !value) return LAM_HIP_EINVAL;
+    if (!strcmp(name, "gemv_variant")) *value = c->opt_gemv_variant;
+    else if (!strcmp(name, "nt_loads")) *value = c->opt_nt;
+    else if (!strcmp(name, "force_generic")) *value = c->opt_generic;
+    else return LAM_HIP_EINVAL;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,489 @@
+// lam_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the dense CG hot path.
+//
+// Reference counterparts (semantics only; nothing here is derived from that code):
+//   gemv / partialDot / reduce / dot / divide / axpy / minusaxpy / xpby CUDA kernels,
+//   /root/reference/challenge/main/LAM/src/GPU/distributed/ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:34-238
+//   and the CPU members dot/axpby/gemv, LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:446-508.
+//
+// Design:
+//   * one CG iteration = 3 launches on a shard:
+//       gemv_tile_kernel   Ap_loc = A_loc p          (+ per-block partials of p.Ap)
+//       update_xr_kernel   alpha = rr/(p.Ap); x += alpha p; r -= alpha Ap   (+ partials of r.r)
+//       update_p_kernel    rr' = r.r; beta = rr'/rr; stop test; p_slice = r + beta p  (stored into
+//                          every shard's replicated p)
+//     alpha, beta, rr, the stop flag and the iteration counter live in device memory
+//     (CgScalars); the host never has to read a scalar to enqueue the next iteration.
+//   * all reductions are two-stage and fixed-order (no floating-point atomics): results are
+//     bit-reproducible run to run and identical on every shard.
+//   * GEMV is HBM-bound (0.25 flop/B in fp64): each wave streams R matrix rows with 16-byte
+//     non-temporal loads (1 KiB per wave instruction), the matching tile of p is staged once per
+//     workgroup in LDS and shared by 4 waves x R rows, lane partials are combined with wave64
+//     shuffles.  Tiles are visited in a per-workgroup rotated order so that concurrently running
+//     workgroups do not all sit at the same column offset of a power-of-two row pitch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+namespace lam {
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxShards = 16;
+
+struct CgScalars {
+    double bb;        // b.b
+    double rr[2];     // ping-pong: iteration k reads rr[(k+1)&1], writes rr[k&1]
+    double pAp;       // last p.Ap (diagnostics)
+    double alpha;
+    double beta;
+    int iters;        // last completed iteration (the converging one once stop is set)
+    int stop;         // set by update_p_kernel when sqrt(rr/bb) < rel_error
+};
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over the workgroup; every thread returns the same value.  Fixed order -> deterministic.
+__device__ __forceinline__ double block_sum(double v, double *s_red /*[kWaves]*/)
+{
+    v = wave_sum(v);
+    __syncthreads();  // s_red may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = s_red[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; w++) t += s_red[w];
+    return t;
+}
+
+// Sum of src[0..n) by one workgroup, identical on every workgroup that calls it.
+__device__ __forceinline__ double block_sum_array(const double *__restrict__ src, int n, double *s_red)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) v += src[i];
+    return block_sum(v, s_red);
+}
+
+template <typename TA> struct MatVec;  // 16-byte vector of matrix elements
+template <> struct MatVec<double> {
+    typedef double vec_t __attribute__((ext_vector_type(2)));
+    static constexpr int N = 2;
+    static __device__ __forceinline__ double get(const vec_t &v, int i) { return v[i]; }
+};
+template <> struct MatVec<float> {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    static constexpr int N = 4;
+    static __device__ __forceinline__ float get(const vec_t &v, int i) { return v[i]; }
+};
+// bf16 storage: 8 elements per 16 bytes, widened to fp32 by a 16-bit shift (exact)
+template <> struct MatVec<__hip_bfloat16> {
+    typedef unsigned short vec_t __attribute__((ext_vector_type(8)));
+    static constexpr int N = 8;
+    static __device__ __forceinline__ float get(const vec_t &v, int i)
+    {
+        return __uint_as_float(((unsigned)v[i]) << 16);
+    }
+};
+
+// scalar widening of one matrix element to the vector type
+template <typename TV> __device__ __forceinline__ TV widen(double v) { return (TV)v; }
+template <typename TV> __device__ __forceinline__ TV widen(float v) { return (TV)v; }
+template <typename TV> __device__ __forceinline__ TV widen(__hip_bfloat16 v)
+{
+    return (TV)__uint_as_float(((unsigned)*reinterpret_cast<const unsigned short *>(&v)) << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMV  y_loc = A_loc * p        (A_loc: nrows x n row-major, p: n, y_loc: nrows)
+// ---------------------------------------------------------------------------------------------
+template <typename TA, typename TV>
+struct GemvArgs {
+    const TA *A;
+    const TV *p;            // full-length vector
+    TV *y;                  // local rows
+    double *partial;        // [gridDim.x] per-workgroup partial of sum_r y[r]*p[row0+r]; may be null
+    const CgScalars *sc;    // may be null; if sc->stop the kernel does nothing
+    uint64_t nrows;         // local rows
+    uint64_t n;             // columns (= global N)
+    uint64_t row0;          // global index of local row 0 (for the fused dot)
+};
+
+// Fast path: n % (16/sizeof(TA)) == 0, A and p 16-byte aligned.
+//   workgroup = 4 waves, wave w owns rows (4*blockIdx+w)*R .. +R-1, all n columns.
+//   TILE elements of p live in LDS at a time.
+template <typename TA, typename TV, int R, int TILE, bool NT, int UNROLL>
+__global__ void __launch_bounds__(kBlock)
+gemv_tile_kernel(GemvArgs<TA, TV> a)
+{
+    using MV = MatVec<TA>;
+    using avec_t = typename MV::vec_t;
+    constexpr int VEC = MV::N;
+    constexpr int STEP = 64 * VEC;          // columns one wave instruction covers
+    static_assert(TILE % STEP == 0, "tile must be a whole number of wave steps");
+    constexpr int STEPS = TILE / STEP;
+
+    __shared__ __attribute__((aligned(16))) TV s_p[TILE];
+    __shared__ double s_red[kWaves];
+
+    if (a.sc != nullptr && a.sc->stop) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint64_t n = a.n;
+    const uint64_t row_first = ((uint64_t)blockIdx.x * kWaves + wave) * R;
+
+    const TA *rowp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint64_t row = row_first + r;
+        if (row >= a.nrows) row = a.nrows - 1;   // keep loads in bounds; result discarded below
+        rowp[r] = a.A + row * n + (uint64_t)lane * VEC;
+    }
+    TV acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = (TV)0;
+
+    const uint32_t ntiles = (uint32_t)((n + TILE - 1) / TILE);
+    uint32_t tt = blockIdx.x % ntiles;               // rotated start
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint64_t c0 = (uint64_t)tt * TILE;
+        const uint32_t cols = (uint32_t)((n - c0 < (uint64_t)TILE) ? (n - c0) : (uint64_t)TILE);
+        __syncthreads();                              // previous tile fully consumed
+        // stage p[c0 .. c0+cols) -- 16-byte loads, cols is a multiple of VEC (>= 16 B of TV too)
+        {
+            constexpr int PV = 16 / sizeof(TV);
+            typedef TV pvec_t __attribute__((ext_vector_type(PV)));
+            const pvec_t *src = reinterpret_cast<const pvec_t *>(a.p + c0);
+            pvec_t *dst = reinterpret_cast<pvec_t *>(s_p);
+            const uint32_t nv = cols / PV;
+            for (uint32_t i = tid; i < nv; i += kBlock) dst[i] = src[i];
+            for (uint32_t i = nv * PV + tid; i < cols; i += kBlock) s_p[i] = a.p[c0 + i];
+        }
+        __syncthreads();
+
+        if (cols == TILE) {
+#pragma unroll UNROLL
+            for (int s = 0; s < STEPS; s++) {
+                avec_t av[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)s * STEP);
+                    av[r] = NT ? __builtin_nontemporal_load(src) : *src;
+                }
+                TV pv[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; i++) pv[i] = s_p[s * STEP + lane * VEC + i];
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
+            }
+        } else {
+            for (uint32_t c = lane * VEC; c < cols; c += STEP) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const avec_t av = *reinterpret_cast<const avec_t *>(rowp[r] + c0 + c - (uint64_t)lane * VEC);
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av, i) * s_p[c + i];
+                }
+            }
+        }
+        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+    }
+
+    // lane partials -> row sums (wave64 butterfly), fused p.Ap partial
+    double dotp = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        TV s = wave_sum(acc[r]);
+        const uint64_t row = row_first + r;
+        if (lane == 0 && row < a.nrows) {
+            a.y[row] = s;
+            dotp += (double)s * (double)a.p[a.row0 + row];
+        }
+    }
+    if (a.partial != nullptr) {
+        __syncthreads();
+        if (lane == 0) s_red[wave] = dotp;
+        __syncthreads();
+        if (tid == 0) {
+            double t = s_red[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; w++) t += s_red[w];
+            a.partial[blockIdx.x] = t;
+        }
+    }
+}
+
+// General path (any n, any alignment): one wave per row, scalar loads, p from global/L2.
+template <typename TA, typename TV>
+__global__ void __launch_bounds__(kBlock)
+gemv_generic_kernel(GemvArgs<TA, TV> a)
+{
+    __shared__ double s_red[kWaves];
+    if (a.sc != nullptr && a.sc->stop) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint64_t row = (uint64_t)blockIdx.x * kWaves + wave;
+    double dotp = 0.0;
+    if (row < a.nrows) {
+        const TA *ar = a.A + row * a.n;
+        TV acc = (TV)0;
+        for (uint64_t c = lane; c < a.n; c += 64) {
+            acc += widen<TV>(ar[c]) * a.p[c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            a.y[row] = acc;
+            dotp = (double)acc * (double)a.p[a.row0 + row];
+        }
+    }
+    if (a.partial != nullptr) {
+        if (lane == 0) s_red[wave] = dotp;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = s_red[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; w++) t += s_red[w];
+            a.partial[blockIdx.x] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector kernels
+// ---------------------------------------------------------------------------------------------
+struct PtrList {                      // destinations of a replicated store (one per shard)
+    void *p[kMaxShards];
+    int n;
+};
+
+// sum src[0..n) with one workgroup and store it at index `slot` of every destination array
+__global__ void __launch_bounds__(kBlock)
+finalize_sum_kernel(const double *__restrict__ src, int n, PtrList dst, int slot, const CgScalars *sc)
+{
+    __shared__ double s_red[kWaves];
+    if (sc != nullptr && sc->stop) return;
+    double t = block_sum_array(src, n, s_red);
+    if (threadIdx.x == 0)
+        for (int j = 0; j < dst.n; j++) reinterpret_cast<double *>(dst.p[j])[slot] = t;
+}
+
+// x = 0, r = b, p_slice = b (into every shard's p), partials of b.b
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+cg_init_kernel(const TV *__restrict__ b, TV *__restrict__ x, TV *__restrict__ r, PtrList pdst,
+               uint64_t row0, uint64_t n_loc, double *__restrict__ partial)
+{
+    __shared__ double s_red[kWaves];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock) {
+        const TV bi = b[i];
+        x[i] = (TV)0;
+        r[i] = bi;
+        for (int j = 0; j < pdst.n; j++) reinterpret_cast<TV *>(pdst.p[j])[row0 + i] = bi;
+        acc += (double)bi * (double)bi;
+    }
+    double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// bb = rr[0] = sum(red); iters = 0; stop = 0
+__global__ void __launch_bounds__(kBlock)
+cg_init_scalars_kernel(const double *__restrict__ red, int nred, CgScalars *sc)
+{
+    __shared__ double s_red[kWaves];
+    double t = block_sum_array(red, nred, s_red);
+    if (threadIdx.x == 0) {
+        sc->bb = t;
+        sc->rr[0] = t;
+        sc->rr[1] = 0.0;
+        sc->pAp = 0.0;
+        sc->alpha = 0.0;
+        sc->beta = 0.0;
+        sc->iters = 0;
+        sc->stop = 0;
+    }
+}
+
+// alpha = rr / p.Ap ; x += alpha p ; r -= alpha Ap ; partials of r.r
+// (axpby(alpha,p,1,x); axpby(-alpha,Ap,1,r); dot(r,r): ConjugateGradient_CPU_MPI_OMP.hpp:107-110)
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
+                 const TV *__restrict__ p_loc, const TV *__restrict__ Ap, TV *__restrict__ x,
+                 TV *__restrict__ r, uint64_t n_loc, double *__restrict__ partial)
+{
+    __shared__ double s_red[kWaves];
+    if (sc->stop) return;
+    const double pAp = block_sum_array(red, nred, s_red);
+    const double rr = sc->rr[(k + 1) & 1];
+    const double alpha_d = rr / pAp;
+    const TV alpha = (TV)alpha_d;
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock) {
+        x[i] = alpha * p_loc[i] + x[i];
+        const TV ri = -alpha * Ap[i] + r[i];
+        r[i] = ri;
+        acc += (double)ri * (double)ri;
+    }
+    double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = t;
+        if (blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
+    }
+}
+
+// rr' = r.r ; beta = rr'/rr ; if sqrt(rr'/bb) < tol: stop (p untouched) else p_slice = r + beta p
+// (ConjugateGradient_CPU_MPI_OMP.hpp:110-114: the test comes BEFORE the p update)
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
+                const TV *__restrict__ r, const TV *__restrict__ p_loc, PtrList pdst, uint64_t row0,
+                uint64_t n_loc, volatile int *host_flags /* pinned host: [0]=iters [1]=stop */)
+{
+    __shared__ double s_red[kWaves];
+    if (sc->stop) return;
+    const double rr_new = block_sum_array(red, nred, s_red);
+    const double rr = sc->rr[(k + 1) & 1];
+    const double bb = sc->bb;
+    const double beta_d = rr_new / rr;
+    const bool stop = sqrt(rr_new / bb) < rel_error;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->rr[k & 1] = rr_new;
+        sc->beta = beta_d;
+        sc->iters = k;
+        if (host_flags != nullptr) {
+            host_flags[0] = k;
+            if (stop) host_flags[1] = 1;
+        }
+    }
+    if (stop) {
+        // every workgroup reaches the same decision from the same bits; a workgroup that starts
+        // after the flag is up returns at the top, which is the same outcome (p is not updated)
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->stop = 1;
+        return;
+    }
+    const TV beta = (TV)beta_d;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock) {
+        const TV pi = r[i] + beta * p_loc[i];
+        for (int j = 0; j < pdst.n; j++) reinterpret_cast<TV *>(pdst.p[j])[row0 + i] = pi;
+    }
+}
+
+// standalone BLAS-1 pieces (lam_hip_dot / lam_hip_axpby and the residual check)
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+dot_partial_kernel(const TV *__restrict__ x, const TV *__restrict__ y, uint64_t n, double *__restrict__ partial)
+{
+    __shared__ double s_red[kWaves];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+        acc += (double)x[i] * (double)y[i];
+    double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+axpby_kernel(TV alpha, const TV *__restrict__ x, TV beta, TV *__restrict__ y, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+        y[i] = alpha * x[i] + beta * y[i];
+}
+
+// partial of sum (b - y)^2 over a slice (true-residual check)
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+resid_partial_kernel(const TV *__restrict__ b, const TV *__restrict__ y, uint64_t n, double *__restrict__ partial)
+{
+    __shared__ double s_red[kWaves];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const double d = (double)b[i] - (double)y[i];
+        acc += d * d;
+    }
+    double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generators (one-off, not on the hot path)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+template <typename TA>
+__device__ __forceinline__ TA to_storage(double v);
+template <> __device__ __forceinline__ double to_storage<double>(double v) { return v; }
+template <> __device__ __forceinline__ float to_storage<float>(double v) { return (float)v; }
+template <> __device__ __forceinline__ __hip_bfloat16 to_storage<__hip_bfloat16>(double v) { return __float2bfloat16((float)v); }
+
+// rows [row0,row0+nrows) of dense tridiag(1,2,1) by GLOBAL row index
+template <typename TA>
+__global__ void __launch_bounds__(kBlock)
+gen_tridiag_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n)
+{
+    const uint64_t total = nrows * n;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t i = idx / n + row0, j = idx % n;
+        double v = 0.0;
+        if (i == j) v = 2.0;
+        else if (i + 1 == j || i == j + 1) v = 1.0;
+        A[idx] = to_storage<TA>(v);
+    }
+}
+
+template <typename TA>
+__global__ void __launch_bounds__(kBlock)
+gen_random_spd_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, uint64_t seed, double cond)
+{
+    const uint64_t total = nrows * n;
+    const double inv_n = 1.0 / (double)n;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t i = idx / n + row0, j = idx % n;
+        double v;
+        if (i == j) {
+            v = 1.0 + (cond - 1.0) * u01(splitmix64(seed ^ splitmix64(i * 2 + 1)));
+        } else {
+            const uint64_t lo = i < j ? i : j, hi = i < j ? j : i;
+            v = (2.0 * u01(splitmix64(seed + splitmix64(lo * n + hi))) - 1.0) * inv_n;
+        }
+        A[idx] = to_storage<TA>(v);
+    }
+}
+
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+gen_rhs_kernel(TV *__restrict__ b, uint64_t row0, uint64_t n_loc, int random, uint64_t seed, double value)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock)
+        b[i] = random ? (TV)(2.0 * u01(splitmix64(seed ^ splitmix64(0xB5ull + row0 + i))) - 1.0) : (TV)value;
+}
+
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+f32_to_bf16_kernel(const float *__restrict__ src, __hip_bfloat16 *__restrict__ dst, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+        dst[i] = __float2bfloat16(src[i]);
+}
+
+}  // namespace lam

@@ -1,0 +1,179 @@
+/*
+ * lam_hip.h -- C ABI of the MI355X-native dense Conjugate-Gradient hot path.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and scalars only (no C++, no torch
+ * types).  The reference has no FFI layer; its operator API is the abstract class
+ * LAM::ConjugateGradient<T> (challenge/main/LAM/src/ConjugateGradient.hpp:9-28) plus the
+ * generate/getter methods of the distributed classes
+ * (LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:31-35,
+ *  LAM/src/GPU/distributed/ConjugateGradient_MultiGPUS_CUDA_NCCL.cuh:37-41).
+ * The C++ classes in 2024-eumaster4hpc-student-challenge_amd/LAM/ implement that class
+ * interface on top of the functions below; every entry point says which reference member
+ * (file:line) it stands in for.  Paths are relative to /root/reference/challenge/main/.
+ *
+ * Conventions
+ *   - return 0 on success, a negative LAM_HIP_E* code on failure; lam_hip_last_error()
+ *     gives the message (HIP / RCCL status text included).  Every HIP and RCCL call is
+ *     checked.  No exceptions cross the ABI.
+ *   - a context owns all device memory, streams, events and the RCCL communicator; host
+ *     buffers passed in are borrowed for the duration of the call only.
+ *   - a context is not thread-safe; one solve at a time (same as the reference classes).
+ *   - "shard" = one block of consecutive matrix rows living on one device, partitioned
+ *     exactly like the reference: shard q of P owns rows [q*(N/P), (q+1)*(N/P)), the last
+ *     shard also takes N%P (LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:176-184).
+ *   - the library never falls back to the CPU: without a usable GPU every compute entry
+ *     point fails with LAM_HIP_ENODEV.
+ */
+#ifndef LAM_HIP_H
+#define LAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAM_HIP_ABI_VERSION 1
+
+/* storage / arithmetic type of the matrix and vectors */
+#define LAM_HIP_F64 0  /* double everywhere (the reference drivers hard-code <double>) */
+#define LAM_HIP_F32 1  /* float storage, float FMA, double only for the reduced scalars */
+#define LAM_HIP_BF16 2 /* bf16 matrix storage, fp32 vectors and accumulation (config 4) */
+
+#define LAM_HIP_EINVAL (-1)  /* bad argument / call order */
+#define LAM_HIP_ENODEV (-2)  /* no usable GPU */
+#define LAM_HIP_EHIP (-3)    /* a HIP call failed */
+#define LAM_HIP_ERCCL (-4)   /* an RCCL call failed */
+#define LAM_HIP_ENOMEM (-5)  /* device or host allocation failed */
+#define LAM_HIP_ESTATE (-6)  /* problem / matrix / rhs not set yet */
+
+#define LAM_HIP_UNIQUE_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+
+typedef struct lam_hip_ctx lam_hip_ctx;
+
+/* What the reference prints per run (test/test_CG_CPU_MPI_OMP.cpp:201-203 and
+ * ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:332-334,424-427), as numbers. */
+typedef struct lam_hip_stats {
+    int32_t num_iters;    /* loop counter on exit: converging iteration, or max_iters+1 at the cap */
+    int32_t converged;    /* solve()'s bool */
+    double rel_err;       /* sqrt(rr/bb), the recursive relative residual */
+    double t_gemv;        /* average seconds per iteration in the GEMV kernel (device time) */
+    double t_iter;        /* average seconds per iteration (wall, whole loop / iterations run) */
+    double t_total;       /* wall seconds of the call */
+    double t_comm_init;   /* seconds spent creating the RCCL communicator (0 if none) */
+    double gemv_bytes;    /* algorithmic bytes one GEMV launch on this rank reads+writes */
+} lam_hip_stats;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+
+int lam_hip_abi_version(void);
+int lam_hip_device_count(int *count);
+
+/* One process driving `n_shards` row shards, shard q on device_ids[q] (device ids may repeat,
+ * which puts several shards on one GPU; device_ids == NULL means 0,1,..,n_shards-1 modulo the
+ * device count).  Shards exchange p slices and partial dot products by direct peer stores
+ * over xGMI.  Stands in for the constructor + device discovery of the single-process class
+ * LAM/src/GPU/local/ConjugateGradient_MultiGPUS_CUDA.cuh:20-22 and, with n_shards == 1, of
+ * LAM/src/GPU/local/ConjugateGradient_GPU_CUDA.cuh. */
+int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device_ids);
+
+/* One process per GPU: this process owns shard `rank` of `nranks` on `device_id`; the per
+ * iteration exchange is RCCL (all-gather of p, all-reduce of the two dot products).
+ * `unique_id` = LAM_HIP_UNIQUE_ID_BYTES bytes obtained from lam_hip_get_unique_id() on one rank
+ * and distributed by the caller (MPI_Bcast, torch.distributed, a file ...), exactly the
+ * bootstrap of ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:306-334 (ncclGetUniqueId + MPI_Bcast +
+ * ncclCommInitRank, timed into the extra CSV column -> lam_hip_stats.t_comm_init). */
+int lam_hip_get_unique_id(void *unique_id_out);
+int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, int nranks,
+                        const void *unique_id);
+
+void lam_hip_destroy(lam_hip_ctx *ctx);
+const char *lam_hip_last_error(const lam_hip_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* ---- problem definition ------------------------------------------------------------------- */
+
+/* Fix N, compute the reference row partition and allocate A (rows_loc x N, row-major, per
+ * shard) and the work vectors.  Stands in for the allocation half of load_matrix_from_file /
+ * generate_matrix (ConjugateGradient_CPU_MPI_OMP.hpp:176-196,214,250-253;
+ * ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:544-568). */
+int lam_hip_set_problem(lam_hip_ctx *ctx, uint64_t n);
+
+int lam_hip_n(const lam_hip_ctx *ctx, uint64_t *n);
+int lam_hip_num_shards(const lam_hip_ctx *ctx, int *total_shards, int *local_shards);
+/* rows of global shard q (any q in [0,total_shards), local or not) */
+int lam_hip_get_partition(const lam_hip_ctx *ctx, int shard, uint64_t *row0, uint64_t *nrows);
+
+/* Copy rows [row0,row0+nrows) of the global matrix (host, row-major, nrows*N elements of the
+ * context dtype; for LAM_HIP_BF16 the host rows are float and are rounded on upload) into the
+ * local shard(s) that own them.  Rows owned by other processes are an error.  Stands in for
+ * the read + H2D copy of load_matrix_from_file (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:
+ * 568-583), with 64-bit counts. */
+int lam_hip_upload_rows(lam_hip_ctx *ctx, uint64_t row0, uint64_t nrows, const void *host_rows);
+/* inverse of upload (tests, and save of generated systems) */
+int lam_hip_download_rows(lam_hip_ctx *ctx, uint64_t row0, uint64_t nrows, void *host_rows);
+
+/* Dense tridiag(1,2,1) filled on device by GLOBAL row index: generate_matrix,
+ * ConjugateGradient_CPU_MPI_OMP.hpp:237-247 / ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:628-714. */
+int lam_hip_generate_tridiag(lam_hip_ctx *ctx);
+/* Dense symmetric strictly diagonally dominant SPD test matrix, generated on device from a
+ * counter-based hash (no reference counterpart; replaces the MKL-based
+ * challenge/main/random_spd_system.cpp for sizes that do not fit a file):
+ *   A[i][j] = A[j][i] = u(seed,min,max)/N, u in [-1,1);  A[i][i] = 1 + (cond-1)*v(seed,i), v in [0,1)
+ * eigenvalues lie in (0, cond+1): `cond` spreads the spectrum so CG does not converge at once. */
+int lam_hip_generate_random_spd(lam_hip_ctx *ctx, uint64_t seed, double cond);
+
+/* b: load_rhs_from_file (ConjugateGradient_CPU_MPI_OMP.hpp:258-305) / generate_rhs (:144-165).
+ * b_host has N elements of the vector dtype (double for F64, float otherwise). */
+int lam_hip_set_rhs(lam_hip_ctx *ctx, const void *b_host);
+int lam_hip_generate_rhs(lam_hip_ctx *ctx, double value);          /* b == value (reference: 1.0) */
+int lam_hip_generate_random_rhs(lam_hip_ctx *ctx, uint64_t seed);  /* b ~ U[-1,1) */
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+
+/* solve(): ConjugateGradient_CPU_MPI_OMP.hpp:71-142 (recurrence, stop test BEFORE the p update,
+ * num_iters = max_iters+1 at the cap).  Returns 0 whether or not it converged; see
+ * stats->converged.  Equivalent to lam_hip_cg_init + lam_hip_cg_iterate(max_iters). */
+int lam_hip_solve(lam_hip_ctx *ctx, int max_iters, double rel_error, lam_hip_stats *stats);
+
+/* x=0, r=p=b, bb=b.b (ConjugateGradient_CPU_MPI_OMP.hpp:82-93). */
+int lam_hip_cg_init(lam_hip_ctx *ctx);
+/* Run up to `iters` further iterations of the loop (:98-116), continuing the iteration count
+ * of earlier calls.  rel_error <= 0 never stops early (the stop test is still evaluated). */
+int lam_hip_cg_iterate(lam_hip_ctx *ctx, int iters, double rel_error, lam_hip_stats *stats);
+
+/* x (N elements of the vector dtype) to the host: the payload of save_result_to_file
+ * (ConjugateGradient_CPU_OMP.hpp:199-217).  In rank mode this is a collective: every rank
+ * must call it and every rank receives the full vector. */
+int lam_hip_get_solution(lam_hip_ctx *ctx, void *x_host);
+/* true relative residual ||b - A x||_2 / ||b||_2 recomputed on device with the GEMV kernel
+ * (collective in rank mode).  Not in the reference; used for parity checks at full size. */
+int lam_hip_true_residual(lam_hip_ctx *ctx, double *rel_res);
+
+/* ---- single operators (reference private members / CUDA kernels, for parity tests, roofline
+ *      probes and callers that want the BLAS pieces) ------------------------------------------ */
+
+/* y = A x with the production GEMV kernel on the context's matrix.  x_host, y_host: N elements
+ * (vector dtype).  Collective in rank mode.  gemv: ConjugateGradient_CPU_MPI_OMP.hpp:482-508,
+ * CUDA gemv kernel ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:185-238. */
+int lam_hip_gemv(lam_hip_ctx *ctx, const void *x_host, void *y_host);
+/* `reps` back-to-back launches of the production GEMV kernel(s) over the local shard(s),
+ * timed with HIP events on the launch stream; *sec_per_gemv = average seconds per launch
+ * (max over local shards).  No reference counterpart (roofline probe). */
+int lam_hip_gemv_only(lam_hip_ctx *ctx, int reps, double *sec_per_gemv);
+/* dot (ConjugateGradient_CPU_MPI_OMP.hpp:446-467; CUDA partialDot+reduce :50-131) and axpby
+ * (:469-480; CUDA axpy/minusaxpy/xpby :133-183) on host vectors of n elements, run on shard 0's
+ * device with the same reduction code the CG kernels use. */
+int lam_hip_dot(lam_hip_ctx *ctx, const void *x_host, const void *y_host, uint64_t n, double *result);
+int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double beta, void *y_host,
+                  uint64_t n);
+
+/* ---- tuning knobs (benchmarks only) -------------------------------------------------------- */
+/* name/value pairs, e.g. "gemv_variant"; unknown names -> LAM_HIP_EINVAL */
+int lam_hip_set_option(lam_hip_ctx *ctx, const char *name, int64_t value);
+int lam_hip_get_option(const lam_hip_ctx *ctx, const char *name, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAM_HIP_H */
