@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/s and GEMV GB/s of the MI355X-native dense CG hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE Conjugate-Gradient iteration (row-sharded GEMV Ap=A.p + the two dot products +
+the x, r, p updates + the per-iteration exchange) on a synthetic dense SPD system that is already
+resident in HBM when the timed region starts.  Workload for every GPU count: BASELINE.json
+configs[2], N=65536 fp64 (34.4 GB, fits one MI355X) -- strong scaling, so the driver's 1/2/4/8
+series is one problem.  The matrix is the device-generated random dense SPD system
+(lam_hip_generate_random_spd, cond=1e6 so CG is still iterating at the end of the run).
+At N=1 GPU the line also carries the configs[1] (N=32768) figures under "also".
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (gemv_tile_kernel):
+achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
+the launch stream inside the timed steps.  `cpu_baseline` (rank 0, N=1 only) times the reference's
+own CPU driver (oracle/_ref, built from /root/reference in the build container) -- or, if that
+binary is missing, the oracle port -- on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "2024-eumaster4hpc-student-challenge_amd"
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def cpu_baseline(sample_n, iters):
+    """Reference CPU path timed on this host's cores (reported baseline, not a target)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    ref = os.path.join(ROOT, "oracle", "_ref", "test_CPU_MPI_OMP.out")
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    if os.path.exists(ref):
+        try:
+            t0 = time.time()
+            out = subprocess.run([ref, "-s", str(sample_n), "-i", str(iters), "-o", "/tmp/_bench_sol.bin"],
+                                 env=env, capture_output=True, text=True, timeout=600, cwd="/tmp")
+            line = out.stdout.replace("\n", "").strip()
+            f = line.split(",")
+            # CSV: N,P,threads,gen_s,avg_gemv,avg_iter,iters,err,total  -- the two averages are divided
+            # by num_iters twice (ConjugateGradient_CPU_MPI_OMP.hpp:119-124) and num_iters is
+            # max_iters+1 on exit, so true seconds/iteration = printed * num_iters^2 / max_iters
+            ni = int(f[6])
+            t_iter = float(f[5]) * ni * ni / iters
+            t_gemv = float(f[4]) * ni * ni / iters
+            return {"value": 1.0 / t_iter, "unit": "cg_iterations/s", "cores": int(f[2]), "kind": "reference",
+                    "sample": f"oracle/_ref/test_CPU_MPI_OMP.out -s {sample_n} -i {iters} (generate mode, fp64, "
+                              f"1 MPI rank x {f[2]} OpenMP threads; {sample_n}x{sample_n} matrix = "
+                              f"{8.0 * sample_n * sample_n / 1e9:.1f} GB/iter)",
+                    "gemv_gbps": 8.0 * sample_n * sample_n / t_gemv / 1e9, "sample_n": sample_n,
+                    "wall_s": time.time() - t0}
+        except Exception as e:   # fall through to the port
+            sys.stderr.write(f"[bench] reference CPU driver failed ({e}); using the oracle port\n")
+    from oracle import pyoracle
+    st = pyoracle.cpu_baseline(sample_n, iters, cores)
+    t_iter = st["t_total"] / iters
+    return {"value": 1.0 / t_iter, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
+            "sample": f"oracle port (cg_oracle.c, OpenMP x{cores}), generate mode N={sample_n} fp64, {iters} iterations",
+            "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
+
+
+def run_config(lam, make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6):
+    s = make_solver()
+    s.generate_random_spd(n, seed, cond)
+    s.generate_random_rhs(seed + 1)
+    s.cg_init()
+    if warmup > 0:
+        s.cg_iterate(warmup, 0.0)
+    barrier()
+    t0 = time.perf_counter()
+    st = s.cg_iterate(steps, 0.0)          # returns after its streams are synchronised
+    barrier()
+    dt = time.perf_counter() - t0
+    return s, st, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=65536, help="matrix order (default: BASELINE configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=32768)
+    ap.add_argument("--cpu-sample-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    lam = importlib.import_module(PKG)
+
+    # The CPU baseline runs a child process, so it goes FIRST: nothing has touched the GPU yet
+    # (a process that has initialised the GPU must not fork+exec on this pool).
+    cb = None
+    if rank == 0 and world == 1 and max(1, args.gpus) == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(args.cpu_sample_n, args.cpu_sample_iters)
+
+    dist = None
+    if world > 1:
+        # torch.distributed is control plane only (rendezvous, barrier, max over ranks); the data
+        # path collectives are RCCL calls inside liblam_hip.so on its own stream.
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        uid = [lam.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        uid = uid[0]
+
+        def make_solver():
+            return lam.Solver(lam.F64, rank=rank, nranks=world, device_id=local_rank, unique_id=uid)
+
+        def barrier():
+            dist.barrier()
+        n_gpus = world
+        parallelism = f"row-sharded x{world}, 1 process/GPU, RCCL all-reduce x2 + all-gather(p) per iteration"
+    else:
+        n_gpus = max(1, args.gpus)
+
+        def make_solver():
+            if n_gpus == 1:
+                return lam.Solver(lam.F64)
+            return lam.Solver(lam.F64, n_shards=n_gpus, device_ids=list(range(n_gpus)))
+
+        def barrier():
+            pass
+        parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores"
+
+    n = args.n
+    s, st, dt = run_config(lam, make_solver, n, args.warmup, args.steps, barrier)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+        tg = torch.tensor([st["t_gemv"]], dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        st["t_gemv"] = float(tg[0])
+    true_res = s.true_residual()
+    s.close()
+
+    ms_per_step = dt / args.steps * 1e3
+    gemv_bytes = st["gemv_bytes"]                 # algorithmic bytes of ONE launch on one GPU
+    achieved = gemv_bytes / st["t_gemv"] / 1e9 if st["t_gemv"] > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"n{n}_p{n_gpus}"
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"dense SPD CG, N={n} fp64 (BASELINE configs[2]), device-generated random "
+                               f"SPD matrix (cond 1e6) + random rhs, {args.steps} fixed iterations",
+                   "n": n, "parallelism": parallelism,
+                   "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
+        "gemv_ms": st["t_gemv"] * 1e3,
+        "gemv_gbps_per_gpu": achieved,
+        "gemv_gbps_aggregate": achieved * n_gpus,
+        "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res,
+        "roofline": {"bound": "hbm", "kernel": "gemv_tile_kernel<double,double,4,4096,nt>",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": gemv_bytes},
+    }
+
+    if rank == 0 and n_gpus == 1 and world == 1:
+        # configs[1]: N=32768 on the same GPU, same run
+        s2, st2, dt2 = run_config(lam, make_solver, 32768, args.warmup, args.steps, barrier)
+        s2.close()
+        out["also"] = {"workload": "N=32768 fp64 (BASELINE configs[1])", "value": args.steps / dt2,
+                       "ms_per_step": dt2 / args.steps * 1e3, "gemv_ms": st2["t_gemv"] * 1e3,
+                       "gemv_gbps": st2["gemv_bytes"] / st2["t_gemv"] / 1e9,
+                       "roofline_frac": st2["gemv_bytes"] / st2["t_gemv"] / 1e9 / HBM_PEAK_GBPS}
+        if cb is not None:
+            # same unit as `value`, scaled to the workload's N (bytes per iteration scale with N^2)
+            cb["value_at_sample_n"] = cb["value"]
+            cb["value"] = cb["value"] * (cb["sample_n"] / float(n)) ** 2
+            cb["sample"] += f"; value = measured it/s x ({cb['sample_n']}/{n})^2 to the workload's N"
+            out["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,8 +11,9 @@ Tolerances (fp64; SURVEY.md section 8c, from the reference's own run-to-run spre
                       184), 21..23 on n=16 (23), 109..111 on n=64 (110); the reference's own result
                       files show 358 vs 359 and 306 vs 307-308 for identical inputs.
   CG final residual   printed recursive residual < tol, true residual ||b-Ax||/||b|| <= 2*tol (+1e-13)
-  CG solution         ||x - x_ref||_2 / ||x_ref||_2 <= 1e-8 (cond ~1e3 fixtures at tol 1e-9)
-  generate mode       printed error within 1e-6 relative of the reference's value
+  CG solution         ||x - x_ref||_2 <= (||b-Ax|| + ||b-Ax_ref||) / lambda_min(A)  (rigorous, since
+                      x - x_ref = A^-1 (r_ref - r)), and <= 1e-6 relative; fixed-iteration runs 1e-9
+  generate mode       printed error equal to the reference CSV value to its 6 printed digits (<= 5e-6 rel)
 """
 import math
 import os
@@ -97,9 +98,17 @@ def _check_against_golden(lam, oracle, g, shards):
         assert abs(st["num_iters"] - ref_iters) <= max(3, 0.02 * ref_iters), (g["tag"], st["num_iters"])
         assert st["rel_err"] < g["tol"]
         assert true_res <= 2 * g["tol"] + 1e-13
-        assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 1e-8
         # independent check of the residual on the host
-        assert np.linalg.norm(b - A @ x) / np.linalg.norm(b) <= 2 * g["tol"] + 1e-13
+        res = np.linalg.norm(b - A @ x)
+        assert res / np.linalg.norm(b) <= 2 * g["tol"] + 1e-13
+        # solution vector: both x and the reference's x_ref solve the system only to their residuals,
+        # so x - x_ref = A^-1 (r_ref - r) and ||x - x_ref|| <= (||r|| + ||r_ref||) / lambda_min(A).
+        # That bound is rigorous; it evaluates to ~1e-7 relative on these cond~1e3, tol=1e-9 fixtures.
+        lam_min = np.linalg.eigvalsh(A)[0]
+        bound = (res + np.linalg.norm(b - A @ x_ref)) / lam_min
+        err = np.linalg.norm(x - x_ref)
+        assert err <= 1.01 * bound, (g["tag"], err, bound)
+        assert err / np.linalg.norm(x_ref) <= 1e-6, (g["tag"], err)
     else:
         # fixed iteration count, far from convergence: everything is well conditioned
         assert st["num_iters"] == g["max_iters"] + 1
@@ -134,7 +143,7 @@ def test_cg_gen_mode_golden(lam, golden):
             x = s.solution()
         assert st["num_iters"] == g["iters_printed"], (g, st)
         if g["rel_err_printed"] > 1e-10:
-            assert abs(st["rel_err"] / g["rel_err_printed"] - 1) < 2e-6, (g, st)   # 6 printed digits
+            assert abs(st["rel_err"] / g["rel_err_printed"] - 1) < 5.1e-6, (g, st)   # cout prints 6 digits: half a unit of the 6th is up to 5e-6 relative
         else:
             assert st["rel_err"] < tol
             # converged: x solves tridiag(1,2,1) x = 1
@@ -145,7 +154,11 @@ def test_cg_gen_mode_golden(lam, golden):
 
 
 def test_cg_matches_oracle_iteration_by_iteration(lam, oracle):
-    """Fixed iteration counts on a random SPD system: residual and x track the oracle."""
+    """Fixed iteration counts on a random SPD system: residual and x track the oracle.
+
+    Tolerances come from the reference algorithm's own sensitivity to summation order on this system
+    (oracle at 1 thread vs the oracle with 4/8 threads or 3 emulated ranks): <= 1.6e-14 in the residual
+    and <= 2.4e-12 in x up to k=40, then chaotic (4e-3 / 4e-6 at k=60: orthogonality is lost)."""
     n = 384
     rng = np.random.default_rng(9)
     q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
@@ -155,12 +168,13 @@ def test_cg_matches_oracle_iteration_by_iteration(lam, oracle):
     with lam.Solver(lam.F64) as s:
         s.set_matrix(A)
         s.set_rhs(b)
-        for k in (1, 2, 5, 20, 60):
+        for k, tol_res, tol_x in ((1, 1e-13, 1e-13), (2, 1e-13, 1e-13), (5, 1e-13, 1e-13), (20, 1e-12, 1e-12),
+                                  (40, 1e-11, 1e-10), (60, 5e-2, 5e-5)):
             s.solve(k, 1e-30)
             x_ref, st_ref = oracle.cg_solve(A, b, k, 1e-30)
             assert s.stats["num_iters"] == k + 1 == st_ref["num_iters"]
-            assert abs(s.stats["rel_err"] / st_ref["rel_err"] - 1) < 1e-8
-            assert np.linalg.norm(s.solution() - x_ref) / np.linalg.norm(x_ref) < 1e-9
+            assert abs(s.stats["rel_err"] / st_ref["rel_err"] - 1) < tol_res, k
+            assert np.linalg.norm(s.solution() - x_ref) / np.linalg.norm(x_ref) < tol_x, k
 
 
 def test_cg_iterate_continues(lam):
