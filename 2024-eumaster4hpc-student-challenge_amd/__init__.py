@@ -6,6 +6,6 @@ tests and bench.py; the host-side drop-in for the reference's C++ classes lives 
 gfx950 GPU, every compute call raises.
 """
 from ._capi import (  # noqa: F401
-    LamHipError, Stats, Solver, build, lib, lib_path, device_count, get_unique_id,
+    LamHipError, Stats, Solver, build, lib, lib_path, device_count, get_unique_id, partition,
     F64, F32, BF16,
 )

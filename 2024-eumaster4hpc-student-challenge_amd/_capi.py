@@ -69,6 +69,7 @@ def lib():
             "lam_hip_destroy": ([vp], None),
             "lam_hip_last_error": ([vp], C.c_char_p),
             "lam_hip_set_problem": ([vp, u64], i32),
+            "lam_hip_partition": ([u64, i32, i32, C.POINTER(u64), C.POINTER(u64)], i32),
             "lam_hip_n": ([vp, C.POINTER(u64)], i32),
             "lam_hip_num_shards": ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
             "lam_hip_get_partition": ([vp, i32, C.POINTER(u64), C.POINTER(u64)], i32),
@@ -113,6 +114,15 @@ def get_unique_id():
     if rc != 0:
         raise LamHipError(rc, (lib().lam_hip_last_error(None) or b"").decode())
     return buf.raw
+
+
+def partition(n, num_shards, shard):
+    """Rows (row0, nrows) of shard `shard` of `num_shards` -- the reference's block-row rule."""
+    r0, nr = C.c_uint64(), C.c_uint64()
+    rc = lib().lam_hip_partition(n, num_shards, shard, C.byref(r0), C.byref(nr))
+    if rc != 0:
+        raise LamHipError(rc, "bad partition arguments")
+    return r0.value, nr.value
 
 
 def _read_bin(path, dtype):

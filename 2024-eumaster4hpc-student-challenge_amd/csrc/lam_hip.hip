@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -276,7 +277,7 @@ int sync_all(lam_hip_ctx *c)
 int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop)
 {
     const int L = (int)c->sh.size();
-    if (c->total_shards == 1) return 0;
+    if (!c->rank_mode && c->total_shards == 1) return 0;
     if (c->rank_mode) {
         ShardBase &s = c->sh[0];
         PtrList dst; dst.n = 1; dst.p[0] = second ? s.gather_b : s.gather_a;
@@ -311,7 +312,7 @@ int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop
 
 void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, const double **red, int *nred)
 {
-    if (c->total_shards == 1) {
+    if (!c->rank_mode && c->total_shards == 1) {
         *red = use_gemv_part ? s.part_gemv : s.part_vec;
         *nred = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
     } else if (c->rank_mode) {
@@ -327,7 +328,7 @@ void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, c
 int gather_p_step(lam_hip_ctx *c)
 {
     const int L = (int)c->sh.size();
-    if (c->total_shards == 1) return 0;
+    if (!c->rank_mode && c->total_shards == 1) return 0;
     if (c->rank_mode) {
         ShardBase &s = c->sh[0];
         const uint64_t base = c->n / (uint64_t)c->nranks;
@@ -503,16 +504,24 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     c->total_shards = nranks;
     c->rank = rank;
     c->nranks = nranks;
-    c->rank_mode = nranks > 1;
+    // LAM_HIP_FORCE_RCCL=1 keeps the RCCL exchange even for a single rank (a 1-rank communicator):
+    // lets a one-GPU box exercise every collective call of the multi-rank path
+    const char *force = getenv("LAM_HIP_FORCE_RCCL");
+    const bool forced = force && *force && strcmp(force, "0") != 0;
+    c->rank_mode = nranks > 1 || forced;
     c->sh.resize(1);
     c->sh[0].index = rank;
     c->sh[0].dev = device_id;
     int rc = create_common(c.get());
     if (rc != 0) { for (auto &s : c->sh) free_shard(s); return rc; }
-    if (nranks > 1) {
+    if (c->rank_mode) {
         const double t0 = now_s();
         ncclUniqueId id;
-        memcpy(&id, unique_id, sizeof id);
+        if (unique_id) memcpy(&id, unique_id, sizeof id);
+        else if (ncclGetUniqueId(&id) != ncclSuccess) {
+            for (auto &s : c->sh) free_shard(s);
+            return fail(nullptr, LAM_HIP_ERCCL, "ncclGetUniqueId failed");
+        }
         (void)hipSetDevice(device_id);
         ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
         if (r != ncclSuccess) {
@@ -584,6 +593,13 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
     }
     LAMCHK(sync_all(c));
     c->have_problem = true;
+    return 0;
+}
+
+int lam_hip_partition(uint64_t n, int num_shards, int shard, uint64_t *row0, uint64_t *nrows)
+{
+    if (!row0 || !nrows || num_shards < 1 || shard < 0 || shard >= num_shards) return LAM_HIP_EINVAL;
+    partition(n, num_shards, shard, row0, nrows);
     return 0;
 }
 
@@ -778,7 +794,10 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         const int k = k_first + i;
         const int slot = i % kLag;
         if (i >= kLag) {
-            // the iteration enqueued kLag steps ago is done: harvest its GEMV time and stop flag
+            // The iteration enqueued kLag steps ago is done: harvest its GEMV time and stop flag.
+            // The flag is stored by update_p_kernel before that iteration's event, so a stop at loop
+            // index j is seen exactly at i = j + kLag on every rank: all ranks enqueue the same
+            // number of (no-op) iterations and their collectives stay matched.
             LAMCHK(set_dev(c, s0));
             HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
             float ms = 0.f;

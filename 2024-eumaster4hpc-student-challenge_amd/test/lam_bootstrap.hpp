@@ -1,0 +1,118 @@
+// Launcher glue for the one-process-per-GPU driver: who am I, and how do the ranks agree on the
+// 128-byte RCCL unique id.  The reference does this with MPI_Comm_rank/size + MPI_Bcast
+// (/root/reference/challenge/main/LAM/src/GPU/distributed/ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:
+// 320-327) and picks the device by hashing host names (:502-514).  MPI is not guaranteed next to an
+// MI355X node, so the default is launcher-agnostic: rank/size/local rank from the environment
+// (torchrun: RANK/WORLD_SIZE/LOCAL_RANK; MPICH/hydra: PMI_RANK/PMI_SIZE/MPI_LOCALRANKID; Open MPI:
+// OMPI_COMM_WORLD_*; Slurm: SLURM_PROCID/SLURM_NTASKS/SLURM_LOCALID) and the id through a file that
+// rank 0 publishes atomically (single node; the path can be put on a shared filesystem).  Compile
+// with -DLAM_USE_MPI to use MPI_Bcast instead.
+#ifndef LAM_BOOTSTRAP_HPP
+#define LAM_BOOTSTRAP_HPP
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include <unistd.h>
+
+#include "../../include/lam_hip.h"
+
+#ifdef LAM_USE_MPI
+#include <mpi.h>
+#endif
+
+namespace lam_bootstrap
+{
+
+struct Launch {
+    int rank = 0, size = 1, local_rank = 0;
+    char unique_id[LAM_HIP_UNIQUE_ID_BYTES] = {0};
+    std::string id_file;   // rendezvous file (rank 0 removes it once the communicator exists)
+};
+
+inline int env_int(std::initializer_list<const char *> names, int dflt)
+{
+    for (const char *n : names) {
+        const char *v = getenv(n);
+        if (v && *v) return atoi(v);
+    }
+    return dflt;
+}
+
+inline bool init(int *argc, char ***argv, Launch &L)
+{
+#ifdef LAM_USE_MPI
+    MPI_Init(argc, argv);
+    MPI_Comm_rank(MPI_COMM_WORLD, &L.rank);
+    MPI_Comm_size(MPI_COMM_WORLD, &L.size);
+    MPI_Comm local;
+    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, L.rank, MPI_INFO_NULL, &local);
+    MPI_Comm_rank(local, &L.local_rank);
+    MPI_Comm_free(&local);
+    if (L.size > 1) {
+        if (L.rank == 0 && lam_hip_get_unique_id(L.unique_id) != 0) return false;
+        MPI_Bcast(L.unique_id, LAM_HIP_UNIQUE_ID_BYTES, MPI_BYTE, 0, MPI_COMM_WORLD);
+    }
+    return true;
+#else
+    (void)argc; (void)argv;
+    L.rank = env_int({"RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID"}, 0);
+    L.size = env_int({"WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS"}, 1);
+    L.local_rank = env_int({"LOCAL_RANK", "MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}, L.rank);
+    if (L.size <= 1) return true;
+    std::string path;
+    if (const char *p = getenv("LAM_RCCL_ID_FILE")) path = p;
+    else {
+        const char *job = getenv("LAM_JOB_ID");
+        if (!job) job = getenv("MASTER_PORT");
+        if (!job) job = getenv("SLURM_JOB_ID");
+        if (!job) job = getenv("PMI_ID");   // best effort; set LAM_JOB_ID for concurrent jobs
+        path = std::string("/tmp/lam_rccl_id.") + (job ? job : "default");
+    }
+    L.id_file = path;
+    if (L.rank == 0) {
+        if (lam_hip_get_unique_id(L.unique_id) != 0) return false;
+        const std::string tmp = path + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(L.unique_id, 1, LAM_HIP_UNIQUE_ID_BYTES, f) != LAM_HIP_UNIQUE_ID_BYTES) return false;
+        fclose(f);
+        return rename(tmp.c_str(), path.c_str()) == 0;
+    }
+    for (int tries = 0; tries < 6000; tries++) {   // up to 60 s
+        FILE *f = fopen(path.c_str(), "rb");
+        if (f) {
+            const size_t got = fread(L.unique_id, 1, LAM_HIP_UNIQUE_ID_BYTES, f);
+            fclose(f);
+            if (got == LAM_HIP_UNIQUE_ID_BYTES) return true;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    fprintf(stderr, "rank %d: timed out waiting for %s\n", L.rank, path.c_str());
+    return false;
+#endif
+}
+
+// Call after the communicator has been created on this rank (ncclCommInitRank is collective, so by
+// then every rank has read the id): rank 0 removes the rendezvous file so that a later job with the
+// same id cannot pick up a stale one.
+inline void communicator_ready(const Launch &L)
+{
+    if (L.rank == 0 && !L.id_file.empty()) unlink(L.id_file.c_str());
+}
+
+inline void finalize(const Launch &L)
+{
+#ifdef LAM_USE_MPI
+    (void)L;
+    MPI_Finalize();
+#else
+    (void)L;
+#endif
+}
+
+}  // namespace lam_bootstrap
+#endif

@@ -1,0 +1,152 @@
+// test_CG_MultiGPUS_HIP_RCCL.out -- one process per GPU, RCCL over xGMI.  Drop-in for the
+// reference's getopt-style distributed drivers test_CG_MultiGPUS_CUDA_NCCL.out / _MPI.out /
+// test_CPU_MPI_OMP.out (/root/reference/challenge/main/test/test_CG_CPU_MPI_OMP.cpp:205-291 -- the
+// three differ only in the class name).  Same flags (-A -b | -s, -o -i -e -v -h), same defaults
+// (io/matrix.bin io/rhs.bin io/sol.bin 10000 1e-9), same one-line CSV on stdout:
+//   N, procs, threads, load_or_gen_s, comm_init_s, avg_gemv_s, avg_iter_s, iters, rel_err, cg_total_s
+// (the comm_init column is the NCCL variant's, ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:332-334).
+// Differences, all deliberate: the per-iteration averages are true averages (the CPU variant's
+// are divided by num_iters twice, CPU_MPI_OMP.hpp:119-124); cg_total_s is not truncated to whole
+// seconds in generate mode (test_CG_CPU_MPI_OMP.cpp:173-178); running with neither -s nor -A/-b
+// prints the usage and returns 1 instead of returning an uninitialised value (:281-291).
+// Extensions: -r <seed> -c <cond> generate the seeded dense random SPD system of size -s.
+// Launch: 1 rank = just run it; N ranks = any launcher that exports RANK/WORLD_SIZE/LOCAL_RANK
+// (or PMI_*/OMPI_*/SLURM_*), e.g. `mpiexec -n 8` or `torchrun --no-python`; see lam_bootstrap.hpp.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include <unistd.h>
+
+#include "LAM.hpp"
+#include "lam_bootstrap.hpp"
+
+namespace
+{
+void usage(const char *exe)
+{
+    printf("Usage: %s [ (-A -b | -s) -o -e -i -h -v]\n", exe);
+    printf("Options:\n");
+    printf("  -A <file>       Read matrix from file\n");
+    printf("  -b <file>       Read right hand side from file\n");
+    printf("  -o <file>       Write solution to file\n");
+    printf("  -i <int>        Maximum number of iterations\n");
+    printf("  -e <float>      Relative error\n");
+    printf("  -s <int>        Generate matrix of size n x n\n");
+    printf("  -r <seed>       with -s: seeded dense random SPD system instead of tridiag(1,2,1)\n");
+    printf("  -c <float>      with -r: spread of the spectrum (default 1e4)\n");
+    printf("  -v              Verbose mode\n");
+    printf("  -h              Show this help message\n");
+}
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    lam_bootstrap::Launch L;
+    if (!lam_bootstrap::init(&argc, &argv, L)) {
+        fprintf(stderr, "bootstrap failed: %s\n", lam_hip_last_error(nullptr));
+        return 1;
+    }
+    const char *matrix_file = "io/matrix.bin", *rhs_file = "io/rhs.bin", *sol_file = "io/sol.bin";
+    int max_iters = 10000;
+    double rel_error = 1e-9, cond = 1e4;
+    size_t rows = 0;
+    long seed = -1;
+    bool verbose = false, mode_generate = false, mode_load = false;
+    const bool root = L.rank == 0;
+
+    int opt;
+    while ((opt = getopt(argc, argv, "hvA:b:o:i:e:s:r:c:")) != -1) {
+        switch (opt) {
+        case 'A':
+        case 'b':
+            if (mode_generate) {
+                fprintf(stderr, "Option -s cannot be used with -%c.\n", opt);
+                return 1;
+            }
+            mode_load = true;
+            (opt == 'A' ? matrix_file : rhs_file) = optarg;
+            break;
+        case 'o': sol_file = optarg; break;
+        case 'i': max_iters = atoi(optarg); break;
+        case 'e': rel_error = atof(optarg); break;
+        case 's':
+            if (mode_load) {
+                fprintf(stderr, "Option -A and -b cannot be used with -s.\n");
+                return 1;
+            }
+            mode_generate = true;
+            rows = (size_t)atoll(optarg);
+            break;
+        case 'r': seed = atol(optarg); break;
+        case 'c': cond = atof(optarg); break;
+        case 'v': verbose = true; break;
+        case 'h':
+            if (root) usage(argv[0]);
+            return 0;
+        default:
+            if (root) usage(argv[0]);
+            return 1;
+        }
+    }
+    if (!mode_generate && !mode_load) {
+        if (root) usage(argv[0]);
+        return 1;
+    }
+
+    int ndev = 0;
+    if (lam_hip_device_count(&ndev) != 0 || ndev <= 0) {
+        fprintf(stderr, "No GPU: %s\n", lam_hip_last_error(nullptr));
+        return 1;
+    }
+    LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<double> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id);
+    cg.set_csv_output(!verbose);
+    if (cg.context() == nullptr) return 1;      // creates the RCCL communicator (collective)
+    lam_bootstrap::communicator_ready(L);
+
+    using clk = std::chrono::high_resolution_clock;
+    if (verbose && root) {
+        printf("Command line arguments:\n");
+        if (mode_generate) printf("  rows: %zu  (%.3f GB)\n", rows, rows * (double)rows * 8 / 1024.0 / 1024.0 / 1024.0);
+        else printf("  input_file_matrix: %s\n  input_file_rhs:    %s\n", matrix_file, rhs_file);
+        printf("  output_file_sol:   %s\n  max_iters:         %d\n  rel_error:         %e\n", sol_file, max_iters, rel_error);
+        printf("  Number of processes: %d (1 GPU each)\n\n", L.size);
+    }
+    const auto t0 = clk::now();
+    bool ok;
+    if (mode_generate) ok = seed >= 0 ? cg.generate_random_system(rows, (uint64_t)seed, cond) : cg.generate_matrix(rows, rows);
+    else ok = cg.load_matrix_from_file(matrix_file);
+    const double t_load = std::chrono::duration<double>(clk::now() - t0).count();
+    if (!ok) {
+        if (root) fprintf(stderr, "Failed to read matrix\n");
+        return 1;
+    }
+    if (root && !verbose) std::cout << L.size << "," << 1 << "," << t_load << ",";
+    if (verbose && root) printf("Matrix ready in %f s\n", t_load);
+    if (mode_generate) ok = seed >= 0 ? true : cg.generate_rhs();
+    else ok = cg.load_rhs_from_file(rhs_file);
+    if (!ok) {
+        if (root) fprintf(stderr, "Failed to read right hand side\n");
+        return 2;
+    }
+
+    const auto t1 = clk::now();
+    cg.solve(max_iters, rel_error);
+    const double t_cg = std::chrono::duration<double>(clk::now() - t1).count();
+    if (root && !verbose) std::cout << t_cg;
+    if (verbose && root) {
+        const auto &st = cg.stats();
+        printf("%s after %d iterations, relative error %e, %f s (GEMV %.4f ms = %.1f GB/s per GPU)\n",
+               st.converged ? "Converged" : "Did not converge", st.num_iters, st.rel_err, t_cg, st.t_gemv * 1e3,
+               st.t_gemv > 0 ? st.gemv_bytes / st.t_gemv / 1e9 : 0.0);
+    }
+    if (!cg.save_result_to_file(sol_file)) {
+        if (root) fprintf(stderr, "Failed to save solution\n");
+        return 6;
+    }
+    if (verbose && root) printf("Finished successfully\n");
+    if (root) std::cout << std::endl;
+    lam_bootstrap::finalize(L);
+    return 0;
+}

@@ -40,6 +40,12 @@ def cpu_baseline(sample_n, iters):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:   # container CPU share (cgroup v2 quota): the GPU box exposes 256 CPUs but grants 16
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     ref = os.path.join(ROOT, "oracle", "_ref", "test_CPU_MPI_OMP.out")
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
     if os.path.exists(ref):
@@ -93,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=65536, help="matrix order (default: BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (N=32768) run")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     args = ap.parse_args()
@@ -100,7 +107,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        # Import order matters: torch bundles its own ROCm runtime libraries under the same sonames as
+        # /opt/rocm's.  torch first, then liblam_hip.so (which then binds to the already loaded ones)
+        # is the torch-extension order and is clean; the reverse order aborts at interpreter exit.
+        import torch  # noqa: F401
     lam = importlib.import_module(PKG)
+    lam.lib()
 
     # The CPU baseline runs a child process, so it goes FIRST: nothing has touched the GPU yet
     # (a process that has initialised the GPU must not fork+exec on this pool).
@@ -109,7 +123,7 @@ def main():
         cb = cpu_baseline(args.cpu_sample_n, args.cpu_sample_iters)
 
     dist = None
-    if world > 1:
+    if use_dist:
         # torch.distributed is control plane only (rendezvous, barrier, max over ranks); the data
         # path collectives are RCCL calls inside liblam_hip.so on its own stream.
         import torch
@@ -185,7 +199,7 @@ def main():
                      "algorithmic_bytes_per_launch": gemv_bytes},
     }
 
-    if rank == 0 and n_gpus == 1 and world == 1:
+    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_also:
         # configs[1]: N=32768 on the same GPU, same run
         s2, st2, dt2 = run_config(lam, make_solver, 32768, args.warmup, args.steps, barrier)
         s2.close()
@@ -193,6 +207,7 @@ def main():
                        "ms_per_step": dt2 / args.steps * 1e3, "gemv_ms": st2["t_gemv"] * 1e3,
                        "gemv_gbps": st2["gemv_bytes"] / st2["t_gemv"] / 1e9,
                        "roofline_frac": st2["gemv_bytes"] / st2["t_gemv"] / 1e9 / HBM_PEAK_GBPS}
+    if rank == 0 and n_gpus == 1 and world == 1:
         if cb is not None:
             # same unit as `value`, scaled to the workload's N (bytes per iteration scale with N^2)
             cb["value_at_sample_n"] = cb["value"]

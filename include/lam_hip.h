@@ -99,6 +99,10 @@ const char *lam_hip_last_error(const lam_hip_ctx *ctx); /* ctx may be NULL: last
  * ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:544-568). */
 int lam_hip_set_problem(lam_hip_ctx *ctx, uint64_t n);
 
+/* The row partition itself, usable without a context (and without a GPU): rows of shard q of P for
+ * an n x n matrix, ConjugateGradient_CPU_MPI_OMP.hpp:176-184. */
+int lam_hip_partition(uint64_t n, int num_shards, int shard, uint64_t *row0, uint64_t *nrows);
+
 int lam_hip_n(const lam_hip_ctx *ctx, uint64_t *n);
 int lam_hip_num_shards(const lam_hip_ctx *ctx, int *total_shards, int *local_shards);
 /* rows of global shard q (any q in [0,total_shards), local or not) */

@@ -1,0 +1,121 @@
+"""world_size-2 (and 3) `gloo` test of the N>1 protocol, on CPU.
+
+The HIP kernels need a GPU, so this test runs the *exchange protocol* of the rank mode
+(csrc/lam_hip.hip: row partition -> local GEMV on the own row block -> all-reduce of the partial
+p.Ap -> x, r updates on the own slice -> all-reduce of the partial r.r -> p update on the own slice
+-> all-gather of p) with the product's partition function (lam_hip_partition through the C ABI) and
+torch.distributed collectives, the oracle's operators standing in for the device kernels.  It pins
+that the sharded recurrence reproduces the reference's MPI path: bit-identical to the emulated-rank
+oracle at P=2 (a+b is order-independent), to rounding at P=3."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, PKG_NAME
+
+
+def _worker(rank, world, port, n, max_iters, tol, outdir):
+    import importlib
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lam = importlib.import_module(PKG_NAME)
+    from oracle import pyoracle as o
+
+    # control plane used by bench.py: rank 0's opaque id reaches everyone
+    blob = [os.urandom(128) if rank == 0 else None]
+    dist.broadcast_object_list(blob, src=0)
+    ids = [None] * world
+    dist.all_gather_object(ids, blob[0])
+    assert all(i == ids[0] for i in ids) and len(ids[0]) == 128
+
+    row0, nrows = lam.partition(n, world, rank)
+    parts = [lam.partition(n, world, q) for q in range(world)]
+    A_loc = o.tridiag(n, row0, nrows)                 # generate mode: rows by global index
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, n)                          # same on every rank (seeded)
+
+    def allreduce(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0])
+
+    def allgather_p(p_slice):
+        if n % world == 0:
+            out = [torch.empty(n // world, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(p_slice.copy()))
+            return np.concatenate([t.numpy() for t in out])
+        full = np.empty(n)                             # uneven last block: one broadcast per owner
+        for q, (r0, nr) in enumerate(parts):
+            t = torch.from_numpy(p_slice.copy()) if q == rank else torch.empty(nr, dtype=torch.float64)
+            dist.broadcast(t, src=q)
+            full[r0:r0 + nr] = t.numpy()
+        return full
+
+    sl = slice(row0, row0 + nrows)
+    x = np.zeros(nrows); r = b[sl].copy(); p = b.copy()
+    bb = allreduce(o.dot(b[sl], b[sl])); rr = bb
+    k = 1
+    while k <= max_iters:
+        Ap = o.gemv(A_loc, p)
+        alpha = rr / allreduce(o.dot(p[sl], Ap))
+        x = o.axpby(alpha, p[sl], 1.0, x)
+        r = o.axpby(-alpha, Ap, 1.0, r)
+        rr_new = allreduce(o.dot(r, r))
+        beta = rr_new / rr
+        rr = rr_new
+        if np.sqrt(rr / bb) < tol:
+            break
+        p = allgather_p(o.axpby(1.0, r, beta, p[sl]))
+        k += 1
+    xs = [None] * world
+    dist.all_gather_object(xs, x)
+    if rank == 0:
+        np.save(os.path.join(outdir, "x.npy"), np.concatenate(xs))
+        np.save(os.path.join(outdir, "meta.npy"), np.array([k, np.sqrt(rr / bb)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 256), (3, 301)])
+def test_sharded_protocol_matches_reference_mpi_path(world, n, oracle, tmp_path):
+    # plain multiprocessing with the spawn context: the parent (pytest) must not import torch after
+    # liblam_hip.so has been loaded by another test (load order: see bench.py); the workers import
+    # torch first, then the package.
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    port = 29600 + world + (os.getpid() % 200)
+    max_iters, tol = 10000, 1e-9
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, max_iters, tol, str(tmp_path))) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, f"worker exit code {pr.exitcode}"
+    x = np.load(tmp_path / "x.npy")
+    k, err = np.load(tmp_path / "meta.npy")
+    A = oracle.tridiag(n)
+    b = np.random.default_rng(5).uniform(-1, 1, n)
+    x_emul, st_emul = oracle.cg_solve(A, b, max_iters, tol, P=world)
+    x_one, st_one = oracle.cg_solve(A, b, max_iters, tol)
+    assert int(k) == st_emul["num_iters"]
+    assert abs(int(k) - st_one["num_iters"]) <= max(3, 0.02 * st_one["num_iters"])
+    if world == 2:
+        assert np.array_equal(x, x_emul) and err == st_emul["rel_err"]
+    else:
+        np.testing.assert_allclose(x, x_emul, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(A @ x, b, atol=1e-7)
+
+
+def test_partition_function_matches_reference_rule(lam, oracle):
+    for n, P in [(1001, 4), (65536, 8), (7, 7), (513, 2), (10, 3)]:
+        got = [lam.partition(n, P, q) for q in range(P)]
+        assert got == [oracle.partition(n, P, q) for q in range(P)]
+        assert sum(nr for _, nr in got) == n and got[0][0] == 0
+        assert all(got[q][0] + got[q][1] == got[q + 1][0] for q in range(P - 1))
+        assert got[-1][1] == n // P + n % P          # remainder on the LAST shard

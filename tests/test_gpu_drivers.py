@@ -1,0 +1,125 @@
+"""GPU tests of the C++ host side: the drop-in classes (LAM/src/HIP/*.hpp) and the drivers that
+mirror the reference executables, run as real processes and compared with the reference's own
+outputs (tests/golden) -- so these read like running the reference's drivers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+TEST_DIR = os.path.join(ROOT, "2024-eumaster4hpc-student-challenge_amd", "test")
+RCCL_EXE = os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP_RCCL.out")
+ONE_EXE = os.path.join(TEST_DIR, "test_CG_single_GPU.out")
+MULTI_EXE = os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP.out")
+
+
+def _run(cmd, env=None, **kw):
+    e = dict(os.environ)
+    e.pop("RANK", None); e.pop("WORLD_SIZE", None)
+    if env:
+        e.update(env)
+    return subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=300, **kw)
+
+
+def _csv(stdout):
+    return stdout.replace("\n", "").strip().split(",")
+
+
+def test_getopt_driver_generate_mode_matches_reference_csv(golden, tmp_path):
+    """Same flags, same CSV columns (+ the NCCL variant's comm-init column), same iters/err."""
+    for g in golden["gen_mode"]:
+        if g["P"] != 1 or g["n"] > 2048 and "-i" not in g["args"]:
+            continue
+        r = _run([RCCL_EXE, "-s", str(g["n"]), "-o", str(tmp_path / "sol.bin")] + g["args"])
+        assert r.returncode == 0, r.stderr
+        f = _csv(r.stdout)
+        ref = g["csv"].split(",")
+        assert len(f) == len(ref) + 1          # N,P,threads,t_gen,[t_comm_init],t_gemv,t_iter,iters,err,t_total
+        assert f[0] == ref[0] and f[1] == "1"
+        assert int(f[7]) == g["iters_printed"]
+        if g["rel_err_printed"] > 1e-10:
+            assert abs(float(f[8]) / g["rel_err_printed"] - 1) < 1e-5
+        # the solution file holds x (clean header), not the rhs the reference's MPI class writes
+        hdr = np.fromfile(tmp_path / "sol.bin", dtype=np.uint64, count=2)
+        assert hdr.tolist() == [g["n"], 1]
+
+
+def test_getopt_driver_file_mode_against_golden_solution(golden, oracle, tmp_path):
+    g = next(x for x in golden["file_mode"] if x["n"] == 256)
+    sol = tmp_path / "sol.bin"
+    r = _run([RCCL_EXE, "-A", os.path.join(GOLDEN, g["name"] + ".matrix.bin"), "-b",
+              os.path.join(GOLDEN, g["name"] + ".rhs.bin"), "-o", str(sol), "-e", repr(g["tol"])])
+    assert r.returncode == 0, r.stderr
+    f = _csv(r.stdout)
+    assert int(f[0]) == g["n"]
+    assert abs(int(f[7]) - g["iters_printed"]) <= max(3, 0.02 * g["iters_printed"])
+    assert float(f[8]) < g["tol"]
+    x = oracle.read_bin(str(sol)).reshape(-1)
+    x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+
+
+@pytest.mark.parametrize("exe,env", [(ONE_EXE, {}), (MULTI_EXE, {"LAM_NUM_SHARDS": "3"})])
+def test_positional_drivers(golden, oracle, tmp_path, exe, env):
+    """matrix rhs sol max_iters rel_error; prints the reference's 'Converged in K iterations' line."""
+    for g in golden["file_mode"]:
+        if g["n"] < 16:
+            continue
+        sol = tmp_path / "sol.bin"
+        r = _run([exe, os.path.join(GOLDEN, g["name"] + ".matrix.bin"), os.path.join(GOLDEN, g["name"] + ".rhs.bin"),
+                  str(sol), str(g["max_iters"]), repr(g["tol"])], env=env)
+        assert r.returncode == 0, r.stderr
+        assert "Finished successfully" in r.stdout
+        x = oracle.read_bin(str(sol)).reshape(-1)
+        x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
+        if g["converged"]:
+            line = next(l for l in r.stdout.splitlines() if l.startswith("Converged in"))
+            k = int(line.split()[2])
+            assert abs(k - g["iters_printed"]) <= max(3, 0.02 * g["iters_printed"])
+            assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+        else:
+            assert f"Did not converge in {g['max_iters']} iterations" in r.stdout
+            assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-12
+
+
+def test_driver_exit_codes(tmp_path, golden):
+    """1 = matrix problem, 2 = rhs problem (test_CG_CPU_MPI_OMP.cpp:55-59,72-76); usage -> 1."""
+    g = golden["file_mode"][0]
+    m = os.path.join(GOLDEN, g["name"] + ".matrix.bin")
+    assert _run([ONE_EXE, str(tmp_path / "nope.bin")]).returncode == 1
+    other = next(x for x in golden["file_mode"] if x["n"] != g["n"])
+    r = _run([ONE_EXE, m, os.path.join(GOLDEN, other["name"] + ".rhs.bin"), str(tmp_path / "s.bin")])
+    assert r.returncode == 2 and "does not match" in r.stderr
+    assert _run([RCCL_EXE]).returncode == 1
+    assert _run([RCCL_EXE, "-s", "64", "-A", "x"]).returncode == 1     # -s and -A are exclusive
+    assert _run([RCCL_EXE, "-h"]).returncode == 0
+
+
+def test_rank_mode_collectives_single_rank(lam, oracle, monkeypatch):
+    """LAM_HIP_FORCE_RCCL=1 runs every RCCL call of the one-process-per-GPU path (ncclAllReduce x2,
+    ncclAllGather / grouped ncclBroadcast per iteration, the gathers of x) on a 1-rank communicator.
+    The result must be bit-identical to the plain single-shard path (same reduction order)."""
+    n = 1000
+    rng = np.random.default_rng(3)
+    q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
+    A = (q * np.exp(2.0 * rng.uniform(-1, 1, n))) @ q.T
+    A = 0.5 * (A + A.T)
+    b = rng.uniform(-1, 1, n)
+    with lam.Solver(lam.F64) as s:
+        s.set_matrix(A); s.set_rhs(b); s.solve(500, 1e-10)
+        x0, st0 = s.solution(), s.stats
+    monkeypatch.setenv("LAM_HIP_FORCE_RCCL", "1")
+    with lam.Solver(lam.F64, rank=0, nranks=1, device_id=0, unique_id=None) as s:
+        s.set_matrix(A); s.set_rhs(b); s.solve(500, 1e-10)
+        x1, st1 = s.solution(), s.stats
+        assert st1["t_comm_init"] > 0
+        res = s.true_residual()
+        y = s.gemv(b)
+    assert st0["num_iters"] == st1["num_iters"] and st0["rel_err"] == st1["rel_err"]
+    assert np.array_equal(x0, x1)
+    assert res < 2e-10
+    assert np.max(np.abs(y - oracle.gemv(A, b))) <= 1e-13 * np.max(np.abs(A) @ np.abs(b))
