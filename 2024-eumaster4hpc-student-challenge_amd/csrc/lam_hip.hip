@@ -78,9 +78,10 @@ struct lam_hip_ctx {
     std::vector<ShardBase> sh;     // local shards
     std::string err;
     // options
-    int64_t opt_gemv_variant = 0;  // 0 = default tile kernel
+    int64_t opt_gemv_variant = 8;  // production shape: R=1 row per wave, 4096-column p tile in LDS
     int64_t opt_nt = 1;
     int64_t opt_generic = 0;       // force the generic kernel
+    int64_t opt_probe_rows = 0;    // gemv_only: use only the first probe_rows rows of each shard (0 = all)
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
     size_t esz_v() const { return dtype == LAM_HIP_F64 ? 8 : 4; }
@@ -139,17 +140,38 @@ int vec_grid(uint64_t n_loc)
 template <typename TA, typename TV>
 struct Impl {
     static constexpr int VEC = MatVec<TA>::N;
-    // default GEMV shape: R rows per wave, TILE columns of p in LDS
-    static constexpr int R = 4;
-    static constexpr int TILE = 4096;
+
+    // GEMV shapes: {rows per wave R, p-tile columns TILE, p in LDS, rotated tile order}.  Variant 8
+    // (R=1) is the production shape -- measured fastest at N=65536, at N=32768 and on the 8192-row
+    // shard of an 8-way split (profiles/r01_gemv_variant_sweep.txt); the others are selectable with
+    // lam_hip_set_option("gemv_variant") for tuning runs (tools/gemv_probe.py).
+    static constexpr int kNumVariants = 9;
+    static int variant_rows(int v)
+    {
+        static const int rows[kNumVariants] = {4, 2, 8, 4, 4, 2, 4, 4, 1};
+        return rows[v];
+    }
 
     static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic && (c->n % VEC) == 0; }
+    static int variant(const lam_hip_ctx *c)
+    {
+        return (c->opt_gemv_variant >= 0 && c->opt_gemv_variant < kNumVariants) ? (int)c->opt_gemv_variant : 8;
+    }
 
     static int gemv_grid(const lam_hip_ctx *c, uint64_t nrows)
     {
         if (nrows == 0) return 0;
-        const uint64_t rows_per_block = fast_ok(c) ? (uint64_t)kWaves * R : (uint64_t)kWaves;
+        const uint64_t rows_per_block = fast_ok(c) ? (uint64_t)kWaves * variant_rows(variant(c)) : (uint64_t)kWaves;
         return (int)((nrows + rows_per_block - 1) / rows_per_block);
+    }
+
+    template <int R, int TILE, bool LDS, bool ROT>
+    static void launch_tile(const lam_hip_ctx *c, int grid, hipStream_t st, const GemvArgs<TA, TV> &a)
+    {
+        if (c->opt_nt)
+            hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, true, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
+        else
+            hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
     }
 
     static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
@@ -160,10 +182,18 @@ struct Impl {
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
         const int grid = gemv_grid(c, s.nrows);
         if (fast_ok(c)) {
-            if (c->opt_nt)
-                hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, true, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a);
-            else
-                hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+            switch (variant(c)) {
+            default:
+            case 0: launch_tile<4, 4096, true, true>(c, grid, s.stream, a); break;
+            case 1: launch_tile<2, 4096, true, true>(c, grid, s.stream, a); break;
+            case 2: launch_tile<8, 4096, true, true>(c, grid, s.stream, a); break;
+            case 3: launch_tile<4, 2048, true, true>(c, grid, s.stream, a); break;
+            case 4: launch_tile<4, 8192, true, true>(c, grid, s.stream, a); break;
+            case 5: launch_tile<2, 8192, true, true>(c, grid, s.stream, a); break;
+            case 6: launch_tile<4, 4096, false, true>(c, grid, s.stream, a); break;
+            case 7: launch_tile<4, 4096, true, false>(c, grid, s.stream, a); break;
+            case 8: launch_tile<1, 4096, true, true>(c, grid, s.stream, a); break;
+            }
         } else {
             hipLaunchKernelGGL((gemv_generic_kernel<TA, TV>), dim3(grid), dim3(kBlock), 0, s.stream, a);
         }
@@ -941,10 +971,14 @@ int lam_hip_gemv_only(lam_hip_ctx *c, int reps, double *sec)
         using TV = typename ImplTraits<I>::TV;
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
-            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr));  // warm-up
-            HIPCHK(c, hipEventRecord(s.ev_g0[0], s.stream));
-            for (int i = 0; i < reps; i++) LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr));
-            HIPCHK(c, hipEventRecord(s.ev_g1[0], s.stream));
+            const uint64_t nrows_saved = s.nrows;
+            if (c->opt_probe_rows > 0) s.nrows = std::min<uint64_t>(s.nrows, (uint64_t)c->opt_probe_rows);
+            int rc = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);  // warm-up
+            if (rc == 0 && hipEventRecord(s.ev_g0[0], s.stream) != hipSuccess) rc = LAM_HIP_EHIP;
+            for (int i = 0; i < reps && rc == 0; i++) rc = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);
+            if (rc == 0 && hipEventRecord(s.ev_g1[0], s.stream) != hipSuccess) rc = LAM_HIP_EHIP;
+            s.nrows = nrows_saved;
+            if (rc != 0) return rc == LAM_HIP_EHIP ? fail(c, rc, "hipEventRecord failed in gemv_only") : rc;
         }
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
@@ -1085,11 +1119,12 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     if (!c || !name) return LAM_HIP_EINVAL;
     if (!strcmp(name, "gemv_variant")) c->opt_gemv_variant = value;
     else if (!strcmp(name, "nt_loads")) c->opt_nt = value;
-    else if (!strcmp(name, "force_generic")) {
-        c->opt_generic = value;
-        for (auto &s : c->sh)
-            if (c->have_problem) s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
-    } else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
+    else if (!strcmp(name, "force_generic")) c->opt_generic = value;
+    else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
+    else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
+    // the GEMV grid (= number of p.Ap partials the next kernel sums) depends on the kernel shape
+    for (auto &s : c->sh)
+        if (c->have_problem) s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
     return 0;
 }
 
@@ -1099,6 +1134,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     if (!strcmp(name, "gemv_variant")) *value = c->opt_gemv_variant;
     else if (!strcmp(name, "nt_loads")) *value = c->opt_nt;
     else if (!strcmp(name, "force_generic")) *value = c->opt_generic;
+    else if (!strcmp(name, "probe_rows")) *value = c->opt_probe_rows;
     else return LAM_HIP_EINVAL;
     return 0;
 }

@@ -121,7 +121,9 @@ struct GemvArgs {
 // Fast path: n % (16/sizeof(TA)) == 0, A and p 16-byte aligned.
 //   workgroup = 4 waves, wave w owns rows (4*blockIdx+w)*R .. +R-1, all n columns.
 //   TILE elements of p live in LDS at a time.
-template <typename TA, typename TV, int R, int TILE, bool NT, int UNROLL>
+//   USE_LDS = false reads p straight from global memory (L2-resident) instead -- kept as a tuning
+//   variant; ROT = false visits the tiles in natural order.
+template <typename TA, typename TV, int R, int TILE, bool NT, int UNROLL, bool USE_LDS = true, bool ROT = true>
 __global__ void __launch_bounds__(kBlock)
 gemv_tile_kernel(GemvArgs<TA, TV> a)
 {
@@ -132,7 +134,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     static_assert(TILE % STEP == 0, "tile must be a whole number of wave steps");
     constexpr int STEPS = TILE / STEP;
 
-    __shared__ __attribute__((aligned(16))) TV s_p[TILE];
+    __shared__ __attribute__((aligned(16))) TV s_p[USE_LDS ? TILE : 4];
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
@@ -155,10 +157,11 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     for (int r = 0; r < R; r++) acc[r] = (TV)0;
 
     const uint32_t ntiles = (uint32_t)((n + TILE - 1) / TILE);
-    uint32_t tt = blockIdx.x % ntiles;               // rotated start
+    uint32_t tt = ROT ? blockIdx.x % ntiles : 0;     // rotated start
     for (uint32_t t = 0; t < ntiles; t++) {
         const uint64_t c0 = (uint64_t)tt * TILE;
         const uint32_t cols = (uint32_t)((n - c0 < (uint64_t)TILE) ? (n - c0) : (uint64_t)TILE);
+        if constexpr (USE_LDS) {
         __syncthreads();                              // previous tile fully consumed
         // stage p[c0 .. c0+cols) -- 16-byte loads, cols is a multiple of VEC (>= 16 B of TV too)
         {
@@ -171,6 +174,8 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
             for (uint32_t i = nv * PV + tid; i < cols; i += kBlock) s_p[i] = a.p[c0 + i];
         }
         __syncthreads();
+        }
+        const TV *pt = USE_LDS ? (const TV *)s_p : a.p + c0;
 
         if (cols == TILE) {
 #pragma unroll UNROLL
@@ -183,7 +188,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
                 }
                 TV pv[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; i++) pv[i] = s_p[s * STEP + lane * VEC + i];
+                for (int i = 0; i < VEC; i++) pv[i] = pt[s * STEP + lane * VEC + i];
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
@@ -195,7 +200,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
                 for (int r = 0; r < R; r++) {
                     const avec_t av = *reinterpret_cast<const avec_t *>(rowp[r] + c0 + c - (uint64_t)lane * VEC);
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av, i) * s_p[c + i];
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av, i) * pt[c + i];
                 }
             }
         }

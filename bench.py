@@ -193,13 +193,13 @@ def main():
         "gemv_gbps_per_gpu": achieved,
         "gemv_gbps_aggregate": achieved * n_gpus,
         "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res,
-        "roofline": {"bound": "hbm", "kernel": "gemv_tile_kernel<double,double,4,4096,nt>",
+        "roofline": {"bound": "hbm", "kernel": "gemv_tile_kernel<double,double,R=1,TILE=4096,nt,unroll4,lds,rot>",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": gemv_bytes},
     }
 
-    if rank == 0 and n_gpus == 1 and world == 1 and not args.no_also:
+    if rank == 0 and n_gpus == 1 and not use_dist and not args.no_also:
         # configs[1]: N=32768 on the same GPU, same run
         s2, st2, dt2 = run_config(lam, make_solver, 32768, args.warmup, args.steps, barrier)
         s2.close()

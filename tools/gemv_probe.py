@@ -1,23 +1,60 @@
 #!/usr/bin/env python3
-"""GEMV roofline probe: GB/s of the production GEMV kernel (lam_hip_gemv_only) for a few sizes/options."""
-import importlib, os, sys
+"""GEMV roofline probe: GB/s of the GEMV kernel variants (lam_hip_gemv_only), interleaved rounds in
+one process (cdna_hip_programming.md rule 24).   usage: gemv_probe.py [N ...] [--variants 0,1,..] [--dtype f64|f32|bf16]"""
+import argparse, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
+NAMES = {0: "R4 T4096 lds rot (default)", 1: "R2 T4096", 2: "R8 T4096", 3: "R4 T2048", 4: "R4 T8192", 5: "R2 T8192",
+         6: "R4 T4096 p-from-L2", 7: "R4 T4096 no-rot", 8: "R1 T4096"}
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [8192, 32768]
-    for n in sizes:
-        with lam.Solver(lam.F64) as s:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("sizes", nargs="*", type=int, default=[32768])
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8")
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--nt", default="1")
+    ap.add_argument("--rows", type=int, default=0, help="use only the first ROWS rows (a shard of a P-way split)")
+    ap.add_argument("--cg", type=int, default=0, help="also time this many CG iterations per variant")
+    a = ap.parse_args()
+    dt = {"f64": lam.F64, "f32": lam.F32, "bf16": lam.BF16}[a.dtype]
+    es = {"f64": 8, "f32": 4, "bf16": 2}[a.dtype]
+    variants = [int(v) for v in a.variants.split(",")]
+    nts = [int(v) for v in a.nt.split(",")]
+    for n in a.sizes:
+        with lam.Solver(dt) as s:
             s.generate_random_spd(n, 1234, 1e4)
             s.generate_random_rhs(1235)
             s.cg_init()
-            for nt in (1, 0):
-                s.set_option("nt_loads", nt)
-                best = min(s.gemv_only(20) for _ in range(3))
-                print(f"N={n} nt={nt} gemv {best*1e3:.4f} ms  {8.0*n*n/best/1e9:.1f} GB/s  ({8.0*n*n/best/8e12*100:.1f}% of 8 TB/s)", flush=True)
-            s.cg_init()
-            st = s.cg_iterate(100, 0.0)
-            print(f"N={n} CG 100 iters: {st['t_iter']*1e3:.4f} ms/iter, gemv {st['t_gemv']*1e3:.4f} ms, rel_err {st['rel_err']:.3e}", flush=True)
+            res = {}
+            rows = a.rows if a.rows > 0 else n
+            s.set_option("probe_rows", a.rows)
+            for _ in range(a.rounds):
+                for v in variants:
+                    for nt in nts:
+                        s.set_option("gemv_variant", v)
+                        s.set_option("nt_loads", nt)
+                        res.setdefault((v, nt), []).append(s.gemv_only(a.reps))
+            for (v, nt), ts in sorted(res.items()):
+                ts = sorted(ts)
+                med, best = ts[len(ts) // 2], ts[0]
+                gb = es * rows * n / 1e9
+                print(f"N={n} rows={rows} {a.dtype} v{v} nt={nt} [{NAMES.get(v,'?'):26s}] median {med*1e3:8.4f} ms {gb/med:7.1f} GB/s "
+                      f"({gb/med/80:5.1f}% of 8 TB/s)  best {gb/best:7.1f} GB/s", flush=True)
+            if a.cg > 0:
+                for v in variants:
+                    s.set_option("gemv_variant", v)
+                    s.set_option("nt_loads", nts[0])
+                    ts = []
+                    for _ in range(3):
+                        s.cg_init()
+                        s.cg_iterate(5, 0.0)
+                        st = s.cg_iterate(a.cg, 0.0)
+                        ts.append((st["t_iter"], st["t_gemv"]))
+                    ts.sort()
+                    print(f"N={n} {a.dtype} v{v} CG {a.cg} iters: {ts[1][0]*1e3:.4f} ms/iter (gemv {ts[1][1]*1e3:.4f} ms, "
+                          f"other {(ts[1][0]-ts[1][1])*1e6:.1f} us)", flush=True)
 
 if __name__ == "__main__":
     main()
