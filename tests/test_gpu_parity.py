@@ -272,3 +272,54 @@ def test_call_order_errors(lam, tmp_path):
         rhs = tmp_path / "rhs.bin"
         rhs.write_bytes(np.array([63, 1], dtype=np.uint64).tobytes() + np.zeros(63).tobytes())
         assert s.load_rhs_from_file(str(rhs)) is False
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 and bf16-storage variants (BASELINE configs[3]); tolerances stated against an fp64 GEMV on the
+# SAME (already rounded) matrix, as SURVEY.md section 8c prescribes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype_name,eps", [("F32", 2.0 ** -24), ("BF16", 2.0 ** -24)])
+@pytest.mark.parametrize("n", [64, 1000, 4096, 4100])
+def test_gemv_low_precision(lam, oracle, dtype_name, eps, n):
+    dt = getattr(lam, dtype_name)
+    A = _rand_matrix(n, n, n + 7).astype(np.float32)
+    x = np.random.default_rng(n).uniform(-1, 1, n).astype(np.float32)
+    with lam.Solver(dt, n_shards=2, device_ids=[0, 0]) as s:
+        s.set_matrix(A)
+        A_dev = s.download_rows(0, n)          # what the device really holds (bf16-rounded for BF16)
+        y = s.gemv(x)
+    if dtype_name == "F32":
+        assert np.array_equal(A_dev, A)
+    else:
+        assert np.max(np.abs(A_dev - A)) <= 2.0 ** -8 * np.max(np.abs(A))      # bf16 has 8 significant bits
+        assert np.array_equal(A_dev.view(np.uint32) & 0xFFFF, np.zeros_like(A_dev, dtype=np.uint32))
+    y64 = A_dev.astype(np.float64) @ x.astype(np.float64)
+    scale = np.abs(A_dev.astype(np.float64)) @ np.abs(x.astype(np.float64))
+    # fp32 accumulation over n terms in a tree: error <= ~log2(n) eps per unit of scale; allow 32 eps
+    assert np.max(np.abs(y.astype(np.float64) - y64) / scale) <= 32 * eps
+    # the sequential fp32 oracle is itself only this accurate, and agrees within the same bound
+    y_or = oracle.gemv(A_dev, x)
+    assert np.max(np.abs(y.astype(np.float64) - y_or.astype(np.float64)) / scale) <= n * eps
+
+
+@pytest.mark.parametrize("dtype_name", ["F32", "BF16"])
+def test_cg_low_precision(lam, oracle, dtype_name):
+    """fp32 CG on a well-conditioned system: same iteration count as the fp32 oracle to +-max(3,5%),
+    solution within 1e-3 of the fp64 solve of the (rounded) system."""
+    n = 512
+    rng = np.random.default_rng(21)
+    q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
+    A = (q * np.exp(1.0 * rng.uniform(-1, 1, n))) @ q.T
+    A = (0.5 * (A + A.T)).astype(np.float32)
+    b = rng.uniform(-1, 1, n).astype(np.float32)
+    with lam.Solver(getattr(lam, dtype_name)) as s:
+        s.set_matrix(A)
+        A_dev = s.download_rows(0, n)
+        s.set_rhs(b)
+        conv = s.solve(500, 1e-5)
+        x, st = s.solution(), s.stats
+    x_or, st_or = oracle.cg_solve(A_dev, b, 500, 1e-5)
+    assert conv and st_or["converged"]
+    assert abs(st["num_iters"] - st_or["num_iters"]) <= max(3, 0.05 * st_or["num_iters"])
+    x64 = np.linalg.solve(A_dev.astype(np.float64), b.astype(np.float64))
+    assert np.linalg.norm(x - x64) / np.linalg.norm(x64) < 1e-3
