@@ -58,7 +58,9 @@ struct ShardBase {
     CgScalars *sc_host = nullptr;// pinned mirror (filled by an async copy at the end of a call)
     int *host_flags = nullptr;   // pinned, device-visible: [0] last finished iteration, [1] stop
     int gemv_blocks = 0, vec_blocks = 0;
+    hipStream_t comm_stream = nullptr;                          // rank mode: the all-gather of p runs here
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_p = nullptr;  // cross-shard ordering
+    hipEvent_t ev_gathered = nullptr;                           // all-gather on comm_stream finished
     hipEvent_t ev_lag[kLag] = {};
     hipEvent_t ev_g0[kLag] = {}, ev_g1[kLag] = {};              // gemv timing ring
 };
@@ -82,6 +84,9 @@ struct lam_hip_ctx {
     int64_t opt_nt = 1;
     int64_t opt_generic = 0;       // force the generic kernel
     int64_t opt_probe_rows = 0;    // gemv_only: use only the first probe_rows rows of each shard (0 = all)
+    int64_t opt_overlap = 1;       // rank mode: all-gather on its own stream under the own-slice GEMV panel
+    int64_t opt_panel_lo = 0, opt_panel_hi = 0;  // testing: split the CG GEMV into [lo,hi) + the rest
+    bool gather_pending = false;   // an all-gather of p is in flight on comm_stream
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
     size_t esz_v() const { return dtype == LAM_HIP_F64 ? 8 : 4; }
@@ -174,12 +179,24 @@ struct Impl {
             hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
     }
 
-    static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
+    // panel: 0 = whole GEMV; 1 = only columns [lo,hi); 2 = everything but [lo,hi), accumulated onto y
+    static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc,
+                           int panel = 0, uint64_t lo = 0, uint64_t hi = 0)
     {
         if (s.nrows == 0) return 0;
         GemvArgs<TA, TV> a;
         a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
+        a.seg_begin[0] = 0; a.seg_end[0] = c->n; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
+        if (panel == 1) { a.seg_begin[0] = lo; a.seg_end[0] = hi; }
+        else if (panel == 2) {
+            a.accumulate = 1;
+            a.nseg = 0;
+            if (lo > 0) { a.seg_begin[a.nseg] = 0; a.seg_end[a.nseg] = lo; a.nseg++; }
+            if (hi < c->n) { a.seg_begin[a.nseg] = hi; a.seg_end[a.nseg] = c->n; a.nseg++; }
+            if (a.nseg == 0) return 0;
+            if (a.nseg == 1) { a.seg_begin[1] = a.seg_end[1] = 0; }
+        }
         const int grid = gemv_grid(c, s.nrows);
         if (fast_ok(c)) {
             switch (variant(c)) {
@@ -201,6 +218,20 @@ struct Impl {
         return 0;
     }
 };
+
+// Own-slice panel [lo,hi) of the CG GEMV, or lo == hi when the GEMV stays one launch.  Panels need
+// 16-byte aligned segment starts (lo, hi multiples of the vector width) unless the generic kernel runs.
+template <typename I>
+void cg_panel(const lam_hip_ctx *c, const ShardBase &s, uint64_t *lo, uint64_t *hi)
+{
+    *lo = *hi = 0;
+    uint64_t a = 0, b = 0;
+    if (c->opt_panel_hi > c->opt_panel_lo) { a = (uint64_t)c->opt_panel_lo; b = std::min<uint64_t>((uint64_t)c->opt_panel_hi, c->n); }
+    else if (c->rank_mode && c->opt_overlap && c->nranks > 1) { a = s.row0; b = s.row0 + s.nrows; }
+    if (b <= a || (a == 0 && b >= c->n)) return;
+    if (I::fast_ok(c) && (a % I::VEC != 0 || b % I::VEC != 0)) return;
+    *lo = a; *hi = b;
+}
 
 template <typename F>
 int dispatch(lam_hip_ctx *c, F &&f)
@@ -262,9 +293,10 @@ int create_common(lam_hip_ctx *c)
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(nullptr, LAM_HIP_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", s.dev, prop.gcnArchName);
         if (hipSetDevice(s.dev) != hipSuccess) return fail(nullptr, LAM_HIP_EHIP, "hipSetDevice(%d) failed", s.dev);
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess)
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking) != hipSuccess)
             return fail(nullptr, LAM_HIP_EHIP, "hipStreamCreate failed on device %d", s.dev);
-        hipEvent_t *evs[] = {&s.ev_a, &s.ev_b, &s.ev_p};
+        hipEvent_t *evs[] = {&s.ev_a, &s.ev_b, &s.ev_p, &s.ev_gathered};
         for (auto ev : evs)
             if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
@@ -287,6 +319,18 @@ int create_common(lam_hip_ctx *c)
                     return fail(nullptr, LAM_HIP_EHIP, "hipDeviceEnablePeerAccess(%d->%d): %s", s.dev, t.dev, hipGetErrorString(pe));
                 (void)hipGetLastError();
             }
+    return 0;
+}
+
+// make the compute stream wait for an all-gather still in flight on the comm stream
+int settle_gather(lam_hip_ctx *c)
+{
+    if (!c->gather_pending) return 0;
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
+    }
+    c->gather_pending = false;
     return 0;
 }
 
@@ -364,8 +408,26 @@ int gather_p_step(lam_hip_ctx *c)
         const uint64_t base = c->n / (uint64_t)c->nranks;
         const size_t ev = c->esz_v();
         const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+        // The all-gather runs on its own stream so that the next GEMV's own-slice panel overlaps it;
+        // the two streams are tied by events, so operations on the communicator stay totally ordered
+        // (every other collective is enqueued on s.stream after a wait on ev_gathered).
+        hipStream_t cs = c->opt_overlap ? s.comm_stream : s.stream;
+        if (c->opt_overlap) {
+            HIPCHK(c, hipEventRecord(s.ev_p, s.stream));
+            HIPCHK(c, hipStreamWaitEvent(cs, s.ev_p, 0));
+        }
+        struct Done {   // record ev_gathered on every exit path below
+            lam_hip_ctx *c; ShardBase &s; hipStream_t cs;
+            int finish() {
+                if (!c->opt_overlap) return 0;
+                HIPCHK(c, hipEventRecord(s.ev_gathered, cs));
+                c->gather_pending = true;
+                return 0;
+            }
+        } done{c, s, cs};
         if (c->n % (uint64_t)c->nranks == 0) {
-            NCCLCHK(c, ncclAllGather((const char *)s.p + s.row0 * ev, s.p, base, dt, c->comm, s.stream));
+            NCCLCHK(c, ncclAllGather((const char *)s.p + s.row0 * ev, s.p, base, dt, c->comm, cs));
+            return done.finish();
         } else {
             // uneven last block (reference: MPI_Allgatherv): one broadcast per owner
             NCCLCHK(c, ncclGroupStart());
@@ -373,11 +435,11 @@ int gather_p_step(lam_hip_ctx *c)
                 uint64_t r0, nr;
                 partition(c->n, c->nranks, q, &r0, &nr);
                 char *ptr = (char *)s.p + r0 * ev;
-                NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+                NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, cs));
             }
             NCCLCHK(c, ncclGroupEnd());
         }
-        return 0;
+        return done.finish();
     }
     for (int q = 0; q < L; q++) {
         ShardBase &s = c->sh[q];
@@ -432,13 +494,24 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
     return dispatch(c, [&](auto impl) -> int {
         using I = decltype(impl);
         using TV = typename ImplTraits<I>::TV;
-        // 1. GEMV + partial p.Ap
+        // 1. GEMV + partial p.Ap.  With an own-slice panel: that panel first (it only needs the p slice
+        //    this shard wrote itself), then wait for the all-gather, then the remaining columns.
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
+            uint64_t lo, hi;
+            cg_panel<I>(c, s, &lo, &hi);
             HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
-            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+            if (hi > lo) {
+                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, s.sc, 1, lo, hi));
+                if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
+                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi));
+            } else {
+                if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
+                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+            }
             HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
         }
+        c->gather_pending = false;
         LAMCHK(reduce_step(c, false, true, true));
         // 2. x, r update + partial r.r
         for (auto &s : c->sh) {
@@ -574,8 +647,9 @@ void lam_hip_destroy(lam_hip_ctx *c)
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (auto &s : c->sh) {
         free_shard(s);
-        hipEvent_t evs[] = {s.ev_a, s.ev_b, s.ev_p};
+        hipEvent_t evs[] = {s.ev_a, s.ev_b, s.ev_p, s.ev_gathered};
         for (auto e : evs) if (e) (void)hipEventDestroy(e);
+        if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); }
         for (int i = 0; i < kLag; i++) {
             if (s.ev_lag[i]) (void)hipEventDestroy(s.ev_lag[i]);
             if (s.ev_g0[i]) (void)hipEventDestroy(s.ev_g0[i]);
@@ -798,6 +872,7 @@ int lam_hip_cg_init(lam_hip_ctx *c)
     if (!c) return LAM_HIP_EINVAL;
     if (!c->have_matrix || !c->have_rhs) return fail(c, LAM_HIP_ESTATE, "matrix and rhs must be set before cg_init");
     LAMCHK(do_cg_init(c));
+    LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
     for (auto &s : c->sh) s.host_flags[0] = s.host_flags[1] = 0;
     return 0;
@@ -840,6 +915,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         HIPCHK(c, hipEventRecord(s0.ev_lag[slot], s0.stream));
         enq++;
     }
+    LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
     // harvest the GEMV timings still in the ring
     for (int j = std::max(0, enq - kLag); j < enq; j++) {
@@ -1081,7 +1157,7 @@ int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t
         if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
         if (e != hipSuccess) rc = fail(c, LAM_HIP_EHIP, "dot readback: %s", hipGetErrorString(e));
         double t = 0.0;
-        for (int i = 0; i < grid; i++) t += h[i];   // same fixed order as block_sum_array for grid <= 256
+        for (int i = 0; i < grid; i++) t += h[i];   // fixed order: reproducible
         *result = t;
     }
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(part);
@@ -1121,6 +1197,9 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "nt_loads")) c->opt_nt = value;
     else if (!strcmp(name, "force_generic")) c->opt_generic = value;
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
+    else if (!strcmp(name, "overlap")) c->opt_overlap = value;
+    else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
+    else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;
     else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
     // the GEMV grid (= number of p.Ap partials the next kernel sums) depends on the kernel shape
     for (auto &s : c->sh)
@@ -1135,6 +1214,9 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "nt_loads")) *value = c->opt_nt;
     else if (!strcmp(name, "force_generic")) *value = c->opt_generic;
     else if (!strcmp(name, "probe_rows")) *value = c->opt_probe_rows;
+    else if (!strcmp(name, "overlap")) *value = c->opt_overlap;
+    else if (!strcmp(name, "panel_lo")) *value = c->opt_panel_lo;
+    else if (!strcmp(name, "panel_hi")) *value = c->opt_panel_hi;
     else return LAM_HIP_EINVAL;
     return 0;
 }

@@ -69,8 +69,17 @@ __device__ __forceinline__ double block_sum(double v, double *s_red /*[kWaves]*/
 // Sum of src[0..n) by one workgroup, identical on every workgroup that calls it.
 __device__ __forceinline__ double block_sum_array(const double *__restrict__ src, int n, double *s_red)
 {
+    // four independent loads per step: with up to 16384 GEMV partials a one-load-per-step loop is a
+    // chain of L2 latencies (measured 19 us per launch); the order stays fixed, so the sum is still
+    // reproducible and the same in every workgroup
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += kBlock) v += src[i];
+    int i = threadIdx.x;
+#pragma unroll 2
+    for (; i + 3 * kBlock < n; i += 4 * kBlock) {
+        const double a0 = src[i], a1 = src[i + kBlock], a2 = src[i + 2 * kBlock], a3 = src[i + 3 * kBlock];
+        v += (a0 + a1) + (a2 + a3);
+    }
+    for (; i < n; i += kBlock) v += src[i];
     return block_sum(v, s_red);
 }
 
@@ -116,6 +125,14 @@ struct GemvArgs {
     uint64_t nrows;         // local rows
     uint64_t n;             // columns (= global N)
     uint64_t row0;          // global index of local row 0 (for the fused dot)
+    // column panels: the launch covers columns [seg_begin[i], seg_end[i]) for i < nseg (nseg <= 2).
+    // A whole GEMV is one segment [0,n).  In rank mode the iteration's GEMV is two launches: the
+    // panel of the rank's OWN p slice first (runs while the all-gather of the other slices is in
+    // flight), then the rest with accumulate = 1.
+    uint64_t seg_begin[2];
+    uint64_t seg_end[2];
+    int nseg;
+    int accumulate;         // y[row] += ... instead of y[row] = ...
 };
 
 // Fast path: n % (16/sizeof(TA)) == 0, A and p 16-byte aligned.
@@ -156,11 +173,14 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (TV)0;
 
-    const uint32_t ntiles = (uint32_t)((n + TILE - 1) / TILE);
+    const uint32_t ntiles0 = (uint32_t)((a.seg_end[0] - a.seg_begin[0] + TILE - 1) / TILE);
+    const uint32_t ntiles = ntiles0 + (a.nseg > 1 ? (uint32_t)((a.seg_end[1] - a.seg_begin[1] + TILE - 1) / TILE) : 0u);
     uint32_t tt = ROT ? blockIdx.x % ntiles : 0;     // rotated start
     for (uint32_t t = 0; t < ntiles; t++) {
-        const uint64_t c0 = (uint64_t)tt * TILE;
-        const uint32_t cols = (uint32_t)((n - c0 < (uint64_t)TILE) ? (n - c0) : (uint64_t)TILE);
+        const bool second = tt >= ntiles0;
+        const uint64_t c0 = second ? a.seg_begin[1] + (uint64_t)(tt - ntiles0) * TILE : a.seg_begin[0] + (uint64_t)tt * TILE;
+        const uint64_t cend = second ? a.seg_end[1] : a.seg_end[0];
+        const uint32_t cols = (uint32_t)((cend - c0 < (uint64_t)TILE) ? (cend - c0) : (uint64_t)TILE);
         if constexpr (USE_LDS) {
         __syncthreads();                              // previous tile fully consumed
         // stage p[c0 .. c0+cols) -- 16-byte loads, cols is a multiple of VEC (>= 16 B of TV too)
@@ -214,6 +234,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
         TV s = wave_sum(acc[r]);
         const uint64_t row = row_first + r;
         if (lane == 0 && row < a.nrows) {
+            if (a.accumulate) s += a.y[row];
             a.y[row] = s;
             dotp += (double)s * (double)a.p[a.row0 + row];
         }
@@ -245,11 +266,11 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
     if (row < a.nrows) {
         const TA *ar = a.A + row * a.n;
         TV acc = (TV)0;
-        for (uint64_t c = lane; c < a.n; c += 64) {
-            acc += widen<TV>(ar[c]) * a.p[c];
-        }
+        for (int sg = 0; sg < a.nseg; sg++)
+            for (uint64_t c = a.seg_begin[sg] + lane; c < a.seg_end[sg]; c += 64) acc += widen<TV>(ar[c]) * a.p[c];
         acc = wave_sum(acc);
         if (lane == 0) {
+            if (a.accumulate) acc += a.y[row];
             a.y[row] = acc;
             dotp = (double)acc * (double)a.p[a.row0 + row];
         }
