@@ -323,3 +323,28 @@ def test_cg_low_precision(lam, oracle, dtype_name):
     assert abs(st["num_iters"] - st_or["num_iters"]) <= max(3, 0.05 * st_or["num_iters"])
     x64 = np.linalg.solve(A_dev.astype(np.float64), b.astype(np.float64))
     assert np.linalg.norm(x - x64) / np.linalg.norm(x64) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# column-panel GEMV (the split the rank mode uses to overlap the all-gather of p)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,lo,hi,generic", [(4096, 1024, 3072, 0), (4096, 0, 512, 0), (4100, 3586, 4100, 0),
+                                             (12288, 4096, 8192, 0), (1001, 250, 500, 1), (640, 2, 4, 0)])
+def test_cg_with_split_gemv_matches_unsplit(lam, oracle, n, lo, hi, generic):
+    """Own-slice panel [lo,hi) first, the remaining columns accumulated on top: same CG to rounding."""
+    out = []
+    for split in (False, True):
+        with lam.Solver(lam.F64) as s:
+            s.generate_random_spd(n, 77, 300.0)
+            s.generate_random_rhs(78)
+            if generic:
+                s.set_option("force_generic", 1)
+            if split:
+                s.set_option("panel_lo", lo)
+                s.set_option("panel_hi", hi)
+            s.solve(40, 1e-30)
+            out.append((s.solution(), s.stats["rel_err"], s.true_residual()))
+    (x0, e0, t0), (x1, e1, t1) = out
+    assert abs(e1 / e0 - 1) < 1e-10
+    assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-11
+    assert abs(t1 / e1 - 1) < 1e-6
