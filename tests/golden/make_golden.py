@@ -112,6 +112,35 @@ def main():
         })
         print(P, line)
 
+    # ---- 3. heat problem (BASELINE configs[4]) ----
+    # (a) the reference's own Jacobi solver output on small grids (loose sanity fixtures: its stop rule
+    #     is max_diff < 1e-3, so the field is only ~0.1 degree from the discrete solution);
+    # (b) the reference CG (test_CPU_OMP.out) on the dense system written by OUR assembler
+    #     (apps/heat_system.out) for a 12x12 grid -> n = 100.
+    golden["heat"] = []
+    ref_heat = os.path.join(ROOT, "oracle", "_ref", "heat_equation.out")
+    asm = os.path.join(ROOT, "2024-eumaster4hpc-student-challenge_amd", "apps", "heat_system.out")
+    for nx, ny in [(12, 12), (18, 18), (34, 34)]:   # square only: on nx != ny the reference misplaces two corner values (heat_equation.cpp:36-37), one of which lands on a boundary point
+        hp = os.path.join(HERE, f"heat_{nx}x{ny}.jacobi.bin")
+        out = run([ref_heat, str(nx), str(ny), hp])
+        m = re.search(r"converged in (\d+) iterations with max_diff=(\S+)", out)
+        assert m, out
+        golden["heat"].append({"nx": nx, "ny": ny, "jacobi_file": os.path.basename(hp),
+                               "jacobi_iters": int(m.group(1)), "jacobi_max_diff": float(m.group(2))})
+        print("heat", nx, ny, m.group(0))
+    nx = ny = 12
+    mpath = os.path.join(HERE, "heat_12x12.matrix.bin")
+    bpath = os.path.join(HERE, "heat_12x12.rhs.bin")
+    spath = os.path.join(HERE, "heat_12x12_i10000_e1e-09.sol.bin")
+    run([asm, "assemble", str(nx), str(ny), mpath, bpath])
+    out = run([REF_OMP, mpath, bpath, spath, "10000", "1e-9"])
+    m = re.search(r"Converged in (\d+) iterations, relative error is (\S+)", out)
+    assert m, out
+    golden["heat_cg"] = {"nx": nx, "ny": ny, "n": (nx - 2) * (ny - 2), "name": "heat_12x12",
+                         "tag": "heat_12x12_i10000_e1e-09", "max_iters": 10000, "tol": 1e-9,
+                         "iters_printed": int(m.group(1)), "rel_err_printed": float(m.group(2))}
+    print("heat cg", m.group(0))
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(golden, f, indent=1)
 
