@@ -80,7 +80,7 @@ struct lam_hip_ctx {
     std::vector<ShardBase> sh;     // local shards
     std::string err;
     // options
-    int64_t opt_gemv_variant = 8;  // production shape: R=1 row per wave, 4096-column p tile in LDS
+    int64_t opt_gemv_variant = 10; // production shape: gemv_coop_kernel, 2 rows per workgroup, 4096-column p tile in LDS
     int64_t opt_nt = 1;
     int64_t opt_generic = 0;       // force the generic kernel
     int64_t opt_probe_rows = 0;    // gemv_only: use only the first probe_rows rows of each shard (0 = all)
@@ -146,27 +146,29 @@ template <typename TA, typename TV>
 struct Impl {
     static constexpr int VEC = MatVec<TA>::N;
 
-    // GEMV shapes: {rows per wave R, p-tile columns TILE, p in LDS, rotated tile order}.  Variant 8
-    // (R=1) is the production shape -- measured fastest at N=65536, at N=32768 and on the 8192-row
-    // shard of an 8-way split (profiles/r01_gemv_variant_sweep.txt); the others are selectable with
+    // GEMV shapes.  Variants 0-8: gemv_tile_kernel {rows per wave, p-tile columns, p in LDS, rotated
+    // tile order}; 9-18: gemv_coop_kernel {rows per workgroup, tile, waves}.  Variant 10 (cooperative
+    // rows, 2 rows per 4-wave workgroup) is the production shape -- measured fastest at N=65536 and
+    // N=32768 (profiles/r01_gemv_variant_sweep.txt); the others stay selectable with
     // lam_hip_set_option("gemv_variant") for tuning runs (tools/gemv_probe.py).
-    static constexpr int kNumVariants = 9;
-    static int variant_rows(int v)
+    static constexpr int kNumVariants = 19;
+    // rows per WORKGROUP of each variant (variants 9.. are the cooperative-row shape: R rows per workgroup)
+    static int variant_rows_per_block(int v)
     {
-        static const int rows[kNumVariants] = {4, 2, 8, 4, 4, 2, 4, 4, 1};
+        static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 2, 2, 2, 4, 3};
         return rows[v];
     }
 
     static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic && (c->n % VEC) == 0; }
     static int variant(const lam_hip_ctx *c)
     {
-        return (c->opt_gemv_variant >= 0 && c->opt_gemv_variant < kNumVariants) ? (int)c->opt_gemv_variant : 8;
+        return (c->opt_gemv_variant >= 0 && c->opt_gemv_variant < kNumVariants) ? (int)c->opt_gemv_variant : 10;
     }
 
     static int gemv_grid(const lam_hip_ctx *c, uint64_t nrows)
     {
         if (nrows == 0) return 0;
-        const uint64_t rows_per_block = fast_ok(c) ? (uint64_t)kWaves * variant_rows(variant(c)) : (uint64_t)kWaves;
+        const uint64_t rows_per_block = fast_ok(c) ? (uint64_t)variant_rows_per_block(variant(c)) : (uint64_t)kWaves;
         return (int)((nrows + rows_per_block - 1) / rows_per_block);
     }
 
@@ -180,6 +182,15 @@ struct Impl {
     }
 
     // panel: 0 = whole GEMV; 1 = only columns [lo,hi); 2 = everything but [lo,hi), accumulated onto y
+    template <int R, int TILE = 4096, int WAVES = 4, int UNROLL = 4>
+    static void launch_coop(const lam_hip_ctx *c, int grid, hipStream_t st, const GemvArgs<TA, TV> &a)
+    {
+        if (c->opt_nt)
+            hipLaunchKernelGGL((gemv_coop_kernel<TA, TV, R, TILE, true, UNROLL, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, a);
+        else
+            hipLaunchKernelGGL((gemv_coop_kernel<TA, TV, R, TILE, false, UNROLL, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, a);
+    }
+
     static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc,
                            int panel = 0, uint64_t lo = 0, uint64_t hi = 0)
     {
@@ -210,6 +221,16 @@ struct Impl {
             case 6: launch_tile<4, 4096, false, true>(c, grid, s.stream, a); break;
             case 7: launch_tile<4, 4096, true, false>(c, grid, s.stream, a); break;
             case 8: launch_tile<1, 4096, true, true>(c, grid, s.stream, a); break;
+            case 9: launch_coop<1>(c, grid, s.stream, a); break;
+            case 10: launch_coop<2>(c, grid, s.stream, a); break;
+            case 11: launch_coop<4>(c, grid, s.stream, a); break;
+            case 12: launch_coop<8>(c, grid, s.stream, a); break;
+            case 13: launch_coop<2, 4096, 8>(c, grid, s.stream, a); break;
+            case 14: launch_coop<2, 8192, 16, 4>(c, grid, s.stream, a); break;
+            case 15: launch_coop<2, 8192, 8, 8>(c, grid, s.stream, a); break;
+            case 16: launch_coop<2, 8192, 4, 8>(c, grid, s.stream, a); break;
+            case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
+            case 18: launch_coop<3>(c, grid, s.stream, a); break;
             }
         } else {
             hipLaunchKernelGGL((gemv_generic_kernel<TA, TV>), dim3(grid), dim3(kBlock), 0, s.stream, a);
@@ -679,7 +700,7 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         for (auto v : vecs) HIPCHK(c, hipMalloc(v, s.nrows * ev + 16));
         s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
         // worst case over kernel variants (generic kernel: 4 rows per workgroup)
-        const int gemv_blocks_max = (int)((s.nrows + kWaves - 1) / kWaves) + 1;
+        const int gemv_blocks_max = (int)s.nrows + 1;
         s.vec_blocks = vec_grid(s.nrows);
         HIPCHK(c, hipMalloc((void **)&s.part_gemv, sizeof(double) * (size_t)gemv_blocks_max));
         HIPCHK(c, hipMalloc((void **)&s.part_vec, sizeof(double) * kVecBlocksMax));

@@ -252,6 +252,125 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     }
 }
 
+// Cooperative-row variant: the 4 waves of a workgroup stream the SAME R rows, wave w taking every
+// 4th 1-KiB step, so a workgroup reads 4 KiB contiguous per row per super-step and the chip has
+// 4x fewer concurrent row streams than the wave-per-row shape (DRAM page locality experiment).
+// The row sums are combined across waves through LDS in a fixed order.
+template <typename TA, typename TV, int R, int TILE, bool NT, int UNROLL, int WAVES = 4>
+__global__ void __launch_bounds__(WAVES * 64)
+gemv_coop_kernel(GemvArgs<TA, TV> a)
+{
+    using MV = MatVec<TA>;
+    using avec_t = typename MV::vec_t;
+    constexpr int VEC = MV::N;
+    constexpr int STEP = 64 * VEC;
+    static_assert(TILE % (STEP * WAVES) == 0, "tile must be a whole number of workgroup super-steps");
+    constexpr int WSTEPS = TILE / (STEP * WAVES);
+    constexpr int NTHREADS = WAVES * 64;    // steps per wave per tile
+
+    __shared__ __attribute__((aligned(16))) TV s_p[TILE];
+    __shared__ TV s_part[R][WAVES];
+    __shared__ double s_dot[R];
+
+    if (a.sc != nullptr && a.sc->stop) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint64_t n = a.n;
+    const uint64_t row_first = (uint64_t)blockIdx.x * R;
+    const uint32_t woff = (uint32_t)wave * STEP + (uint32_t)lane * VEC;   // this lane's column inside a super-step
+
+    const TA *rowp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint64_t row = row_first + r;
+        if (row >= a.nrows) row = a.nrows - 1;
+        rowp[r] = a.A + row * n + woff;
+    }
+    TV acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = (TV)0;
+
+    const uint32_t ntiles0 = (uint32_t)((a.seg_end[0] - a.seg_begin[0] + TILE - 1) / TILE);
+    const uint32_t ntiles = ntiles0 + (a.nseg > 1 ? (uint32_t)((a.seg_end[1] - a.seg_begin[1] + TILE - 1) / TILE) : 0u);
+    uint32_t tt = blockIdx.x % ntiles;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const bool second = tt >= ntiles0;
+        const uint64_t c0 = second ? a.seg_begin[1] + (uint64_t)(tt - ntiles0) * TILE : a.seg_begin[0] + (uint64_t)tt * TILE;
+        const uint64_t cend = second ? a.seg_end[1] : a.seg_end[0];
+        const uint32_t cols = (uint32_t)((cend - c0 < (uint64_t)TILE) ? (cend - c0) : (uint64_t)TILE);
+        __syncthreads();
+        {
+            constexpr int PV = 16 / sizeof(TV);
+            typedef TV pvec_t __attribute__((ext_vector_type(PV)));
+            const pvec_t *src = reinterpret_cast<const pvec_t *>(a.p + c0);
+            pvec_t *dst = reinterpret_cast<pvec_t *>(s_p);
+            const uint32_t nv = cols / PV;
+            for (uint32_t i = tid; i < nv; i += NTHREADS) dst[i] = src[i];
+            for (uint32_t i = nv * PV + tid; i < cols; i += NTHREADS) s_p[i] = a.p[c0 + i];
+        }
+        __syncthreads();
+        if (cols == TILE) {
+#pragma unroll UNROLL
+            for (int s = 0; s < WSTEPS; s++) {
+                avec_t av[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)s * (STEP * WAVES));
+                    av[r] = NT ? __builtin_nontemporal_load(src) : *src;
+                }
+                TV pv[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; i++) pv[i] = s_p[s * (STEP * WAVES) + woff + i];
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
+            }
+        } else {
+            for (uint32_t c = woff; c < cols; c += STEP * WAVES) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const avec_t av = *reinterpret_cast<const avec_t *>(rowp[r] + c0 + c - woff);
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av, i) * s_p[c + i];
+                }
+            }
+        }
+        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        TV s = wave_sum(acc[r]);
+        if (lane == 0) s_part[r][wave] = s;
+    }
+    __syncthreads();
+    if (tid < R) {
+        const uint64_t row = row_first + tid;
+        double d = 0.0;
+        if (row < a.nrows) {
+            TV s = s_part[tid][0];
+#pragma unroll
+            for (int w = 1; w < WAVES; w++) s += s_part[tid][w];
+            if (a.accumulate) s += a.y[row];
+            a.y[row] = s;
+            d = (double)s * (double)a.p[a.row0 + row];
+        }
+        s_dot[tid] = d;
+    }
+    if (a.partial != nullptr) {
+        __syncthreads();
+        if (tid == 0) {
+            double t = s_dot[0];
+#pragma unroll
+            for (int r = 1; r < R; r++) t += s_dot[r];
+            a.partial[blockIdx.x] = t;
+        }
+    }
+}
+
 // General path (any n, any alignment): one wave per row, scalar loads, p from global/L2.
 template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)

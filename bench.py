@@ -13,7 +13,7 @@ series is one problem.  The matrix is the device-generated random dense SPD syst
 (lam_hip_generate_random_spd, cond=1e6 so CG is still iterating at the end of the run).
 At N=1 GPU the line also carries the configs[1] (N=32768) figures under "also".
 
-One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (gemv_tile_kernel):
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (gemv_coop_kernel):
 achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
 the launch stream inside the timed steps.  `cpu_baseline` (rank 0, N=1 only) times the reference's
 own CPU driver (oracle/_ref, built from /root/reference in the build container) -- or, if that
@@ -193,7 +193,7 @@ def main():
         "gemv_gbps_per_gpu": achieved,
         "gemv_gbps_aggregate": achieved * n_gpus,
         "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res,
-        "roofline": {"bound": "hbm", "kernel": "gemv_tile_kernel<double,double,R=1,TILE=4096,nt,unroll4,lds,rot>",
+        "roofline": {"bound": "hbm", "kernel": "gemv_coop_kernel<double,double,R=2,TILE=4096,nt,unroll4,waves4>",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": gemv_bytes},
