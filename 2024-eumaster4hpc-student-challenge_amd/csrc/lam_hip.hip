@@ -80,7 +80,7 @@ struct lam_hip_ctx {
     std::vector<ShardBase> sh;     // local shards
     std::string err;
     // options
-    int64_t opt_gemv_variant = 10; // production shape: gemv_coop_kernel, 2 rows per workgroup, 4096-column p tile in LDS
+    int64_t opt_gemv_variant = -1; // -1 = production shape for the dtype (see Impl::variant)
     int64_t opt_nt = 1;
     int64_t opt_generic = 0;       // force the generic kernel
     int64_t opt_probe_rows = 0;    // gemv_only: use only the first probe_rows rows of each shard (0 = all)
@@ -162,7 +162,10 @@ struct Impl {
     static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic && (c->n % VEC) == 0; }
     static int variant(const lam_hip_ctx *c)
     {
-        return (c->opt_gemv_variant >= 0 && c->opt_gemv_variant < kNumVariants) ? (int)c->opt_gemv_variant : 10;
+        if (c->opt_gemv_variant >= 0 && c->opt_gemv_variant < kNumVariants) return (int)c->opt_gemv_variant;
+        // production shapes: fp64/fp32 -> cooperative rows (variant 10); bf16 storage spends more VALU
+        // per byte (widening) and measures best with 4 rows per wave (variant 0, 6.77 vs 6.40 TB/s)
+        return sizeof(TA) == 2 ? 0 : 10;
     }
 
     static int gemv_grid(const lam_hip_ctx *c, uint64_t nrows)

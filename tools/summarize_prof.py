@@ -16,7 +16,7 @@ def one(pattern):
     f = glob.glob(pattern, recursive=True)
     if not f:
         sys.exit(f"no file matches {pattern}")
-    return f[0]
+    return max(f, key=os.path.getmtime)      # gpurun_out/ accumulates runs: take the newest
 
 def main():
     ap = argparse.ArgumentParser()
