@@ -151,11 +151,12 @@ struct Impl {
     // rows, 2 rows per 4-wave workgroup) is the production shape -- measured fastest at N=65536 and
     // N=32768 (profiles/r01_gemv_variant_sweep.txt); the others stay selectable with
     // lam_hip_set_option("gemv_variant") for tuning runs (tools/gemv_probe.py).
-    static constexpr int kNumVariants = 19;
+    static constexpr int kNumVariants = 23;
     // rows per WORKGROUP of each variant (variants 9.. are the cooperative-row shape: R rows per workgroup)
     static int variant_rows_per_block(int v)
     {
-        static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 2, 2, 2, 4, 3};
+        static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 2, 2, 2, 4, 3,
+                                                  /* 19-22: MFMA bf16 experiment (bf16 storage only) */ 8, 8, 16, 4};
         return rows[v];
     }
 
@@ -234,6 +235,17 @@ struct Impl {
             case 16: launch_coop<2, 8192, 4, 8>(c, grid, s.stream, a); break;
             case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
             case 18: launch_coop<3>(c, grid, s.stream, a); break;
+            case 19: case 20: case 21: case 22:
+                if constexpr (sizeof(TA) == 2) {
+                    const int v = variant(c);
+                    if (v == 19) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+                    else if (v == 20) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 1>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+                    else if (v == 21) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<4, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+                    else hipLaunchKernelGGL((gemv_mfma_bf16_kernel<1, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+                } else {
+                    return fail(c, LAM_HIP_EINVAL, "gemv_variant 19-22 (MFMA) exist for LAM_HIP_BF16 only");
+                }
+                break;
             }
         } else {
             hipLaunchKernelGGL((gemv_generic_kernel<TA, TV>), dim3(grid), dim3(kBlock), 0, s.stream, a);

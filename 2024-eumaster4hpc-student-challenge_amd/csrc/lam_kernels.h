@@ -371,6 +371,149 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA experiment for the bf16-storage GEMV (BASELINE configs[3]): can the matrix cores take the
+// widening + FMA work off the VALU?  A wave loads 1 KiB = 512 contiguous bf16 of ONE matrix row
+// (perfectly coalesced, exactly like the VALU kernels) and feeds the raw bytes as the A fragment of
+// v_mfma_f32_32x32x16_bf16: lane l (r = l&31, h = l>>5) holds A[r][8h+j] = row[c + 8l + j].  The B
+// fragment is the bf16 image of p at the SAME columns, B[8h+j][r] = p[c + 8l + j], so
+//     D[m][n] = sum_{h,j} row[c + 8(32h+m) + j] * p[c + 8(32h+n) + j]
+// and the DIAGONAL D[m][m] is the partial dot product of lanes m and m+32: trace(D) accumulated over
+// the row is the row's dot product.  31/32 of the MFMA flops are discarded -- they are free, the
+// kernel stays HBM-bound.  p is fp32: SPLIT = 3 feeds it as three bf16 terms (p = hi + mid + lo
+// exactly, 8 mantissa bits each), i.e. three MFMAs per KiB and fp32-exact products; SPLIT = 1 rounds
+// p to bf16 (classical bf16 x bf16 -> fp32 GEMV).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int R, int TILE, bool NT, int SPLIT>
+__global__ void __launch_bounds__(kBlock)
+gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
+{
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    constexpr int STEP = 512;                       // bf16 elements per wave instruction (1 KiB)
+    static_assert(TILE % STEP == 0, "tile must be a whole number of wave steps");
+    constexpr int STEPS = TILE / STEP;
+
+    __shared__ __attribute__((aligned(16))) unsigned short s_pb[SPLIT][TILE];
+    __shared__ double s_red[kWaves];
+
+    if (a.sc != nullptr && a.sc->stop) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint64_t n = a.n;
+    const uint64_t row_first = ((uint64_t)blockIdx.x * kWaves + wave) * R;
+
+    const __hip_bfloat16 *rowp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        uint64_t row = row_first + r;
+        if (row >= a.nrows) row = a.nrows - 1;
+        rowp[r] = a.A + row * n + (uint64_t)lane * 8;
+    }
+    mfma_f32x16 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[r][i] = 0.f;
+    float tail[R];                                   // columns of a ragged last tile (VALU)
+#pragma unroll
+    for (int r = 0; r < R; r++) tail[r] = 0.f;
+
+    const uint32_t ntiles0 = (uint32_t)((a.seg_end[0] - a.seg_begin[0] + TILE - 1) / TILE);
+    const uint32_t ntiles = ntiles0 + (a.nseg > 1 ? (uint32_t)((a.seg_end[1] - a.seg_begin[1] + TILE - 1) / TILE) : 0u);
+    uint32_t tt = blockIdx.x % ntiles;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const bool second = tt >= ntiles0;
+        const uint64_t c0 = second ? a.seg_begin[1] + (uint64_t)(tt - ntiles0) * TILE : a.seg_begin[0] + (uint64_t)tt * TILE;
+        const uint64_t cend = second ? a.seg_end[1] : a.seg_end[0];
+        const uint32_t cols = (uint32_t)((cend - c0 < (uint64_t)TILE) ? (cend - c0) : (uint64_t)TILE);
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)TILE; i += kBlock) {
+            float v = i < cols ? a.p[c0 + i] : 0.f;            // zero padding: padded columns add 0
+            if (SPLIT == 1) {
+                s_pb[0][i] = __builtin_bit_cast(unsigned short, __float2bfloat16(v));
+            } else {
+#pragma unroll
+                for (int sp = 0; sp < SPLIT; sp++) {
+                    const unsigned bits = __float_as_uint(v) & 0xFFFF0000u;   // truncate to bf16: exact remainder
+                    s_pb[sp][i] = (unsigned short)(bits >> 16);
+                    v -= __uint_as_float(bits);
+                }
+            }
+        }
+        __syncthreads();
+        const int full_steps = (int)(cols / STEP);
+        auto step = [&](int s) {
+            u16x8 av[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u16x8 *src = reinterpret_cast<const u16x8 *>(rowp[r] + c0 + (uint64_t)s * STEP);
+                av[r] = NT ? __builtin_nontemporal_load(src) : *src;
+            }
+#pragma unroll
+            for (int sp = 0; sp < SPLIT; sp++) {
+                const u16x8 bv = *reinterpret_cast<const u16x8 *>(&s_pb[sp][s * STEP + lane * 8]);
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, av[r]),
+                                                                     __builtin_bit_cast(mfma_bf16x8, bv), acc[r], 0, 0, 0);
+            }
+        };
+        if (cols == TILE) {
+#pragma unroll 4
+            for (int s = 0; s < STEPS; s++) step(s);
+        } else {
+            for (int s = 0; s < full_steps; s++) step(s);
+        }
+        // ragged remainder of the last tile (cols % 512 != 0): plain VALU on the fp32 p
+        for (uint32_t c = (uint32_t)full_steps * STEP + lane * 8; c < cols; c += STEP) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u16x8 av = *reinterpret_cast<const u16x8 *>(rowp[r] + c0 + c - (uint64_t)lane * 8);
+#pragma unroll
+                for (int i = 0; i < 8; i++) tail[r] += __uint_as_float(((unsigned)av[i]) << 16) * a.p[c0 + c + i];
+            }
+        }
+        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+    }
+
+    // trace of the accumulator: lane l (n = l&31, h = l>>5) holds D[n][n] in register
+    // reg = ((n-4h)&3) + 4*((n-4h)>>3) when ((n-4h)&7) < 4  (C/D map: row = (reg&3) + 8*(reg>>2) + 4h)
+    const int nn = lane & 31, hh = lane >> 5;
+    const int d = nn - 4 * hh;
+    const bool has_diag = d >= 0 && (d & 7) < 4;
+    const int myreg = (d & 3) + 4 * (d >> 3);
+    double dotp = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) v = (has_diag && i == myreg) ? acc[r][i] : v;
+        float s = wave_sum(v + tail[r]);
+        const uint64_t row = row_first + r;
+        if (lane == 0 && row < a.nrows) {
+            if (a.accumulate) s += a.y[row];
+            a.y[row] = s;
+            dotp += (double)s * (double)a.p[a.row0 + row];
+        }
+    }
+    if (a.partial != nullptr) {
+        __syncthreads();
+        if (lane == 0) s_red[wave] = dotp;
+        __syncthreads();
+        if (tid == 0) {
+            double t = s_red[0];
+#pragma unroll
+            for (int w = 1; w < kWaves; w++) t += s_red[w];
+            a.partial[blockIdx.x] = t;
+        }
+    }
+}
+
 // General path (any n, any alignment): one wave per row, scalar loads, p from global/L2.
 template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)

@@ -348,3 +348,26 @@ def test_cg_with_split_gemv_matches_unsplit(lam, oracle, n, lo, hi, generic):
     assert abs(e1 / e0 - 1) < 1e-10
     assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-11
     assert abs(t1 / e1 - 1) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# MFMA experiment kernels for bf16 storage (gemv_variant 19-22): same answers as the VALU kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,tol", [(19, 32 * 2.0 ** -24), (21, 32 * 2.0 ** -24), (22, 32 * 2.0 ** -24),
+                                         (20, 2.0 ** -8)])
+@pytest.mark.parametrize("n", [512, 4096, 4104, 9000])
+def test_mfma_bf16_gemv_matches_fp64(lam, variant, tol, n):
+    """Asymmetric random data, so a wrong fragment/diagonal map cannot cancel.  Variants 19/21/22 feed
+    p as three exact bf16 terms (fp32-faithful); variant 20 rounds p to bf16 (8 significant bits)."""
+    A = _rand_matrix(n, n, n + 3).astype(np.float32)
+    x = np.random.default_rng(n + 4).uniform(-1, 1, n).astype(np.float32)
+    with lam.Solver(lam.BF16) as s:
+        s.set_matrix(A)
+        A_dev = s.download_rows(0, n).astype(np.float64)
+        y_valu = s.gemv(x)
+        s.set_option("gemv_variant", variant)
+        y = s.gemv(x)
+    y64 = A_dev @ x.astype(np.float64)
+    scale = np.abs(A_dev) @ np.abs(x.astype(np.float64))
+    assert np.max(np.abs(y.astype(np.float64) - y64) / scale) <= tol
+    assert np.max(np.abs(y_valu.astype(np.float64) - y64) / scale) <= 32 * 2.0 ** -24
