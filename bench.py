@@ -134,8 +134,10 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         uid = uid[0]
 
+        ndev = lam.device_count()          # counting devices does not initialise the GPU
+
         def make_solver():
-            return lam.Solver(lam.F64, rank=rank, nranks=world, device_id=local_rank, unique_id=uid)
+            return lam.Solver(lam.F64, rank=rank, nranks=world, device_id=local_rank % max(1, ndev), unique_id=uid)
 
         def barrier():
             dist.barrier()
