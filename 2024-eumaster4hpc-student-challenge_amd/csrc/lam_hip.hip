@@ -50,6 +50,8 @@ struct ShardBase {
     void *p = nullptr;           // n (replica)
     void *Ap = nullptr, *x = nullptr, *r = nullptr, *b = nullptr;  // nrows each
     void *tmp = nullptr;         // n: scratch vector (gemv op input / residual)
+    void *r_full = nullptr;      // n: replicated r (rank mode, gather-Ap exchange only)
+    void *ap_gather = nullptr;   // nranks records [Ap slice | double]: gather-Ap exchange only
     double *part_gemv = nullptr; // [gemv_blocks]
     double *part_vec = nullptr;  // [vec_blocks]
     double *gather_a = nullptr;  // [kMaxShards] p.Ap partials of all shards (or the reduced scalar at [0])
@@ -87,6 +89,16 @@ struct lam_hip_ctx {
     int64_t opt_overlap = 1;       // rank mode: all-gather on its own stream under the own-slice GEMV panel
     int64_t opt_panel_lo = 0, opt_panel_hi = 0;  // testing: split the CG GEMV into [lo,hi) + the rest
     bool gather_pending = false;   // an all-gather of p is in flight on comm_stream
+    int64_t opt_exchange = 0;      // rank mode: 0 = all-reduce x2 + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
+    bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
+
+    // gather-Ap needs equal slices and an 8-byte aligned tail for the double
+    bool exchange1_ok() const
+    {
+        return rank_mode && opt_exchange == 1 && n % (uint64_t)nranks == 0 && ((n / (uint64_t)nranks) * esz_v()) % 8 == 0;
+    }
+    uint64_t ex1_base() const { return n / (uint64_t)nranks; }
+    uint64_t ex1_stride_bytes() const { return ex1_base() * esz_v() + 8; }
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
     size_t esz_v() const { return dtype == LAM_HIP_F64 ? 8 : 4; }
@@ -304,8 +316,10 @@ PtrList plist_gather(lam_hip_ctx *c, bool second)
 void free_shard(ShardBase &s)
 {
     (void)hipSetDevice(s.dev);
-    void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc};
+    void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
+                    s.r_full, s.ap_gather};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    s.r_full = s.ap_gather = nullptr;
     if (s.sc_host) (void)hipHostFree(s.sc_host);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     s.host_flags = nullptr;
@@ -499,8 +513,63 @@ namespace {
 template <typename T> struct ImplTraits;
 template <typename TA_, typename TV_> struct ImplTraits<Impl<TA_, TV_>> { using TA = TA_; using TV = TV_; };
 
+// gather-Ap exchange: CG state = x slice, FULL r and p on every rank
+int do_cg_init_exchange1(lam_hip_ctx *c)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+        NCCLCHK(c, ncclAllGather(s.b, s.r_full, c->ex1_base(), dt, c->comm, s.stream));   // r_full = b
+        const int grid = vec_grid(c->n);
+        hipLaunchKernelGGL((cg_init_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (TV *)s.r_full, (TV *)s.p,
+                           (TV *)s.x, c->n, s.nrows, s.part_vec);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc);
+        HIPCHK(c, hipGetLastError());
+        c->k_done = 0;
+        c->cg_ready = true;
+        c->cg_exchange1 = true;
+        return 0;
+    });
+}
+
+int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slot)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TV = typename ImplTraits<I>::TV;
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const uint64_t stride = c->ex1_stride_bytes(), base = c->ex1_base();
+        char *rec = (char *)s.ap_gather + (uint64_t)c->rank * stride;
+        // 1. GEMV straight into this rank's record, then its p.Ap partial behind the slice
+        HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+        LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc));
+        HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+        hipLaunchKernelGGL(finalize_tail_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, s.gemv_blocks,
+                           rec, base * sizeof(TV), (const CgScalars *)s.sc);
+        HIPCHK(c, hipGetLastError());
+        // 2. the iteration's only collective
+        NCCLCHK(c, ncclAllGather(rec, s.ap_gather, stride, ncclChar, c->comm, s.stream));
+        // 3. alpha, x slice, FULL r (+ partials of r.r over the full vector: no collective needed)
+        const int grid = vec_grid(c->n);
+        hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
+                           base, c->nranks, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
+        HIPCHK(c, hipGetLastError());
+        // 4. beta, stop test, FULL p
+        hipLaunchKernelGGL((update_p_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc,
+                           k, rel_error, (const TV *)s.r_full, (TV *)s.p, c->n, (volatile int *)s.host_flags);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    });
+}
+
 int do_cg_init(lam_hip_ctx *c)
 {
+    if (c->exchange1_ok()) return do_cg_init_exchange1(c);
+    c->cg_exchange1 = false;
     return dispatch(c, [&](auto impl) -> int {
         using TV = typename ImplTraits<decltype(impl)>::TV;
         PtrList pl = plist_p(c);
@@ -527,6 +596,7 @@ int do_cg_init(lam_hip_ctx *c)
 
 int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
+    if (c->cg_exchange1) return enqueue_iteration_exchange1(c, k, rel_error, slot);
     return dispatch(c, [&](auto impl) -> int {
         using I = decltype(impl);
         using TV = typename ImplTraits<I>::TV;
@@ -721,6 +791,10 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         HIPCHK(c, hipMalloc((void **)&s.part_vec, sizeof(double) * kVecBlocksMax));
         HIPCHK(c, hipMalloc((void **)&s.gather_a, sizeof(double) * kMaxShards));
         HIPCHK(c, hipMalloc((void **)&s.gather_b, sizeof(double) * kMaxShards));
+        if (c->rank_mode) {
+            HIPCHK(c, hipMalloc(&s.r_full, n * ev + 16));
+            HIPCHK(c, hipMalloc(&s.ap_gather, (size_t)c->nranks * ((n / (uint64_t)c->nranks + 1) * ev + 8) + 16));
+        }
         HIPCHK(c, hipMalloc((void **)&s.sc, sizeof(CgScalars)));
         HIPCHK(c, hipHostMalloc((void **)&s.sc_host, sizeof(CgScalars), hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void **)&s.host_flags, 64, hipHostMallocDefault));
@@ -1234,6 +1308,7 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "force_generic")) c->opt_generic = value;
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
     else if (!strcmp(name, "overlap")) c->opt_overlap = value;
+    else if (!strcmp(name, "exchange")) { c->opt_exchange = value; c->cg_ready = false; }
     else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
     else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;
     else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
@@ -1251,6 +1326,8 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "force_generic")) *value = c->opt_generic;
     else if (!strcmp(name, "probe_rows")) *value = c->opt_probe_rows;
     else if (!strcmp(name, "overlap")) *value = c->opt_overlap;
+    else if (!strcmp(name, "exchange")) *value = c->opt_exchange;
+    else if (!strcmp(name, "exchange_effective")) *value = c->exchange1_ok() ? 1 : 0;
     else if (!strcmp(name, "panel_lo")) *value = c->opt_panel_lo;
     else if (!strcmp(name, "panel_hi")) *value = c->opt_panel_hi;
     else return LAM_HIP_EINVAL;

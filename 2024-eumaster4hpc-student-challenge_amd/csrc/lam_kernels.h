@@ -670,6 +670,101 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "gather-Ap" exchange (rank mode, option exchange = 1): ONE collective per iteration.
+// After the GEMV every rank all-gathers [Ap_slice | its partial of p.Ap] (the reference CPU path also
+// gathers Ap, ConjugateGradient_CPU_MPI_OMP.hpp:505) and then updates FULL-length r and p
+// redundantly -- O(N) work per rank, like the reference's full-length axpby (:476) -- so r.r needs
+// no collective at all.  Layout of the gathered buffer: rank q's record starts at q*stride_bytes:
+// `base` values of TV followed by one double.
+// ---------------------------------------------------------------------------------------------
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+cg_init_full_kernel(TV *__restrict__ r_full /* holds b on entry */, TV *__restrict__ p_full, TV *__restrict__ x,
+                    uint64_t n, uint64_t n_loc, double *__restrict__ partial)
+{
+    __shared__ double s_red[kWaves];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const TV bi = r_full[i];
+        p_full[i] = bi;
+        if (i < n_loc) x[i] = (TV)0;
+        acc += (double)bi * (double)bi;
+    }
+    double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// write this rank's p.Ap partial (sum of the GEMV workgroup partials) behind its Ap slice
+__global__ void __launch_bounds__(kBlock)
+finalize_tail_kernel(const double *__restrict__ src, int n, char *record, uint64_t tail_offset_bytes, const CgScalars *sc)
+{
+    __shared__ double s_red[kWaves];
+    if (sc != nullptr && sc->stop) return;
+    double t = block_sum_array(src, n, s_red);
+    if (threadIdx.x == 0) *reinterpret_cast<double *>(record + tail_offset_bytes) = t;
+}
+
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+update_xr_full_kernel(const char *__restrict__ gathered, uint64_t stride_bytes, uint64_t base, int nranks,
+                      CgScalars *sc, int k, const TV *__restrict__ p_full, TV *__restrict__ x, TV *__restrict__ r_full,
+                      uint64_t n, uint64_t row0, uint64_t n_loc, double *__restrict__ partial)
+{
+    __shared__ double s_red[kWaves];
+    if (sc->stop) return;
+    double pAp = 0.0;                                   // rank order, same on every rank
+    for (int q = 0; q < nranks; q++)
+        pAp += *reinterpret_cast<const double *>(gathered + (uint64_t)q * stride_bytes + base * sizeof(TV));
+    const double rr = sc->rr[(k + 1) & 1];
+    const double alpha_d = rr / pAp;
+    const TV alpha = (TV)alpha_d;
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t q = i / base;
+        const TV api = reinterpret_cast<const TV *>(gathered + q * stride_bytes)[i - q * base];
+        const TV ri = -alpha * api + r_full[i];
+        r_full[i] = ri;
+        acc += (double)ri * (double)ri;
+        if (i >= row0 && i < row0 + n_loc) x[i - row0] = alpha * p_full[i] + x[i - row0];
+    }
+    double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = t;
+        if (blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
+    }
+}
+
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+update_p_full_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
+                     const TV *__restrict__ r_full, TV *__restrict__ p_full, uint64_t n, volatile int *host_flags)
+{
+    __shared__ double s_red[kWaves];
+    if (sc->stop) return;
+    const double rr_new = block_sum_array(red, nred, s_red);
+    const double rr = sc->rr[(k + 1) & 1];
+    const double bb = sc->bb;
+    const double beta_d = rr_new / rr;
+    const bool stop = sqrt(rr_new / bb) < rel_error;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->rr[k & 1] = rr_new;
+        sc->beta = beta_d;
+        sc->iters = k;
+        if (host_flags != nullptr) {
+            host_flags[0] = k;
+            if (stop) host_flags[1] = 1;
+        }
+    }
+    if (stop) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->stop = 1;
+        return;
+    }
+    const TV beta = (TV)beta_d;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+        p_full[i] = r_full[i] + beta * p_full[i];
+}
+
 // standalone BLAS-1 pieces (lam_hip_dot / lam_hip_axpby and the residual check)
 template <typename TV>
 __global__ void __launch_bounds__(kBlock)

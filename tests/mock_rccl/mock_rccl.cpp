@@ -47,7 +47,10 @@ std::mutex g_mu;
 std::map<std::string, World *> g_worlds;
 std::atomic<int> g_ids{1};
 
-size_t dsize(ncclDataType_t t) { return t == ncclDouble ? 8 : (t == ncclFloat ? 4 : 0); }
+size_t dsize(ncclDataType_t t)
+{
+    return t == ncclDouble ? 8 : (t == ncclFloat ? 4 : ((t == ncclChar || t == ncclUint8) ? 1 : 0));
+}
 
 // every rank must be executing the same operation with the same count
 ncclResult_t publish(Comm *c, const void *send, size_t count, int opcode, hipStream_t stream)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs P rank-mode contexts as P threads of this process (all on GPU 0) on top of the mock RCCL that
 is LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl.cpp).  Prints one JSON line.
-usage: run_ranks.py P N mode   with mode in {tridiag, spd}"""
+usage: run_ranks.py P N mode [overlap [exchange]]   with mode in {tridiag, spd}"""
 import importlib, json, os, sys, threading
 import numpy as np
 
@@ -13,6 +13,7 @@ lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 def main():
     P, n, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     overlap = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    exchange = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     uid = lam.get_unique_id()
     assert uid.startswith(b"mock-rccl-"), "the mock is not in front of librccl"
     out = [None] * P
@@ -30,6 +31,7 @@ def main():
                     s.generate_random_rhs(100)
                     tol, iters = 1e-10, 2000
                 s.set_option("overlap", overlap)
+                s.set_option("exchange", exchange)
                 conv = s.solve(iters, tol)
                 x = s.solution()                 # collective
                 res = s.true_residual()          # collective

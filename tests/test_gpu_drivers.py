@@ -122,4 +122,13 @@ def test_rank_mode_collectives_single_rank(lam, oracle, monkeypatch):
     assert st0["num_iters"] == st1["num_iters"] and st0["rel_err"] == st1["rel_err"]
     assert np.array_equal(x0, x1)
     assert res < 2e-10
+    # the single-collective exchange (one ncclAllGather of [Ap | p.Ap] per iteration) through real RCCL
+    with lam.Solver(lam.F64, rank=0, nranks=1, device_id=0, unique_id=None) as s:
+        s.set_matrix(A); s.set_rhs(b)
+        s.set_option("exchange", 1)
+        s.solve(500, 1e-10)
+        x2, st2 = s.solution(), s.stats
+        assert s.true_residual() < 2e-10
+    assert abs(st2["num_iters"] - st0["num_iters"]) <= 1
+    assert np.linalg.norm(x2 - x0) / np.linalg.norm(x0) < 1e-9
     assert np.max(np.abs(y - oracle.gemv(A, b))) <= 1e-13 * np.max(np.abs(A) @ np.abs(b))

@@ -29,19 +29,24 @@ def mock_lib():
     return MOCK
 
 
-@pytest.mark.parametrize("P,n,mode,overlap", [
-    (2, 1024, "tridiag", 1),     # even split, aligned panels
-    (3, 1001, "tridiag", 1),     # odd N: generic kernel; uneven split: grouped broadcasts
-    (4, 4096, "spd", 1),
-    (4, 4096, "spd", 0),         # all-gather on the compute stream
-    (3, 4098, "spd", 1),         # 1366 rows per rank
-    (4, 4102, "spd", 1),         # remainder on the last rank, odd row offsets -> no panel split
-    (8, 8192, "spd", 1),         # the node shape
+@pytest.mark.parametrize("P,n,mode,overlap,exchange", [
+    (2, 1024, "tridiag", 1, 0),     # even split, aligned panels
+    (3, 1001, "tridiag", 1, 0),     # odd N: generic kernel; uneven split: grouped broadcasts
+    (4, 4096, "spd", 1, 0),
+    (4, 4096, "spd", 0, 0),         # all-gather on the compute stream
+    (3, 4098, "spd", 1, 0),         # 1366 rows per rank
+    (4, 4102, "spd", 1, 0),         # remainder on the last rank, odd row offsets -> no panel split
+    (8, 8192, "spd", 1, 0),         # the node shape
+    # exchange = 1: ONE all-gather of [Ap slice | p.Ap partial] per iteration, full-length r and p per rank
+    (2, 1024, "tridiag", 1, 1),
+    (4, 4096, "spd", 1, 1),
+    (8, 8192, "spd", 1, 1),
+    (3, 1001, "tridiag", 1, 1),     # uneven split: falls back to exchange 0
 ])
-def test_rank_mode_multi_rank_on_mock_rccl(mock_lib, P, n, mode, overlap):
+def test_rank_mode_multi_rank_on_mock_rccl(mock_lib, P, n, mode, overlap, exchange):
     env = dict(os.environ, LD_PRELOAD=mock_lib)
-    r = subprocess.run([sys.executable, os.path.join(MOCK_DIR, "run_ranks.py"), str(P), str(n), mode, str(overlap)],
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(MOCK_DIR, "run_ranks.py"), str(P), str(n), mode, str(overlap),
+                        str(exchange)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ranks_identical"], out          # every rank holds the same x, iteration count and residual
