@@ -718,6 +718,7 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     const char *force = getenv("LAM_HIP_FORCE_RCCL");
     const bool forced = force && *force && strcmp(force, "0") != 0;
     c->rank_mode = nranks > 1 || forced;
+    if (const char *ex = getenv("LAM_HIP_EXCHANGE")) c->opt_exchange = atoi(ex);   // default exchange for this context
     c->sh.resize(1);
     c->sh[0].index = rank;
     c->sh[0].dev = device_id;

@@ -172,8 +172,22 @@ int lam_hip_dot(lam_hip_ctx *ctx, const void *x_host, const void *y_host, uint64
 int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double beta, void *y_host,
                   uint64_t n);
 
-/* ---- tuning knobs (benchmarks only) -------------------------------------------------------- */
-/* name/value pairs, e.g. "gemv_variant"; unknown names -> LAM_HIP_EINVAL */
+/* ---- options --------------------------------------------------------------------------------- */
+/* name/value pairs; unknown names -> LAM_HIP_EINVAL.
+ *   "exchange"      rank mode only.  0 (default): per iteration ncclAllReduce(p.Ap), ncclAllReduce(r.r),
+ *                   ncclAllGather(p slices) -- sliced x, r, Ap, replicated p.  1: ONE ncclAllGather of
+ *                   [Ap slice | p.Ap partial] per iteration, r and p kept full-length on every rank and
+ *                   updated redundantly (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505); needs
+ *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  Re-run cg_init/solve
+ *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts.
+ *   "overlap"       rank mode, exchange 0: 1 (default) puts the all-gather of p on a second stream under the
+ *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.
+ *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype; 0..22 = tuning shapes
+ *                   (tools/gemv_probe.py; 19-22 are the MFMA experiment, LAM_HIP_BF16 only).
+ *   "nt_loads"      1 (default) = non-temporal loads for the matrix stream.
+ *   "force_generic" 1 = always use the any-N scalar-load GEMV.
+ *   "probe_rows"    lam_hip_gemv_only: use only the first ROWS rows of a shard (a P-way split's shape).
+ *   "panel_lo/hi"   testing: split the CG GEMV into the column panel [lo,hi) + the rest (accumulated). */
 int lam_hip_set_option(lam_hip_ctx *ctx, const char *name, int64_t value);
 int lam_hip_get_option(const lam_hip_ctx *ctx, const char *name, int64_t *value);
 
