@@ -129,6 +129,8 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # single node: the container hostname may not resolve
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         uid = [lam.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

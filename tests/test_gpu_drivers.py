@@ -132,3 +132,16 @@ def test_rank_mode_collectives_single_rank(lam, oracle, monkeypatch):
     assert abs(st2["num_iters"] - st0["num_iters"]) <= 1
     assert np.linalg.norm(x2 - x0) / np.linalg.norm(x0) < 1e-9
     assert np.max(np.abs(y - oracle.gemv(A, b))) <= 1e-13 * np.max(np.abs(A) @ np.abs(b))
+
+
+def test_mpi_bootstrapped_driver_single_rank(tmp_path):
+    """Optional build (`make mpi`): MPI_Init + MPI_Bcast of the RCCL id, the reference NCCL variant's
+    bootstrap (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:320-327).  One rank under mpiexec."""
+    exe = os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP_RCCL_mpi.out")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("MPI driver not built (make mpi)")
+    r = _run([mpiexec, "-n", "1", exe, "-s", "4096", "-i", "15", "-o", str(tmp_path / "sol.bin")])
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = _csv(r.stdout)
+    assert f[0] == "4096" and int(f[7]) == 16 and abs(float(f[8]) / 0.000368282 - 1) < 1e-5
