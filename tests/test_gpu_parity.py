@@ -371,3 +371,40 @@ def test_mfma_bf16_gemv_matches_fp64(lam, variant, tol, n):
     scale = np.abs(A_dev) @ np.abs(x.astype(np.float64))
     assert np.max(np.abs(y.astype(np.float64) - y64) / scale) <= tol
     assert np.max(np.abs(y_valu.astype(np.float64) - y64) / scale) <= 32 * 2.0 ** -24
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases: smallest systems, one row per shard, invalid sizes
+# ------------------------------------------------------------------------------------------------
+def test_tiny_systems(lam, oracle):
+    with lam.Solver(lam.F64) as s:
+        s.set_matrix(np.array([[2.0]]))
+        s.set_rhs(np.array([3.0]))
+        assert s.solve(10, 1e-12)
+        assert s.stats["num_iters"] == 1 and abs(s.solution()[0] - 1.5) < 1e-15
+    A = np.array([[4.0, 1.0, 0.0], [1.0, 3.0, 1.0], [0.0, 1.0, 2.0]])
+    b = np.array([1.0, 2.0, 3.0])
+    x_ref, st_ref = oracle.cg_solve(A, b, 100, 1e-12)
+    for shards in (1, 3):                              # 3 shards: one row each
+        with lam.Solver(lam.F64, n_shards=shards, device_ids=[0] * shards) as s:
+            s.set_matrix(A)
+            s.set_rhs(b)
+            assert s.solve(100, 1e-12)
+            assert s.stats["num_iters"] == st_ref["num_iters"] == 3      # exact in n steps
+            np.testing.assert_allclose(s.solution(), x_ref, rtol=1e-13)
+
+
+def test_invalid_sizes_are_rejected(lam):
+    with lam.Solver(lam.F64, n_shards=4, device_ids=[0] * 4) as s:
+        with pytest.raises(lam.LamHipError) as e:
+            s.set_problem(0)
+        assert e.value.code == -1
+        with pytest.raises(lam.LamHipError):
+            s.set_problem(3)                           # fewer rows than shards
+        s.set_problem(4)
+        with pytest.raises(lam.LamHipError):
+            s.upload_rows(3, np.zeros((2, 4)))         # rows outside the matrix
+    with pytest.raises(lam.LamHipError):
+        lam.Solver(lam.F64, n_shards=1, device_ids=[99])
+    with pytest.raises(lam.LamHipError):
+        lam.Solver(7)                                  # unknown dtype
