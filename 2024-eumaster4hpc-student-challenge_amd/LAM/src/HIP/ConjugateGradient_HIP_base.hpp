@@ -6,7 +6,7 @@
 // Reference behaviour mirrored (paths under /root/reference/challenge/main/LAM/src/):
 //   load_matrix_from_file  CPU/ConjugateGradient_CPU_OMP.hpp:137-197 (header, square check, messages),
 //                          GPU/distributed/ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:489-585 (each
-//                          owner reads its own row block; here with 64-bit counts and chunked preads)
+//                          owner reads its own row block; here from a read-only mmap, 64-bit counts)
 //   load_rhs_from_file     CPU/ConjugateGradient_CPU_MPI_OMP.hpp:258-305
 //   save_result_to_file    CPU/ConjugateGradient_CPU_OMP.hpp:199-217 -- writes x (the MPI variant
 //                          writes _rhs by mistake, :439; the GPU classes are meant to write x); the
@@ -28,6 +28,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -98,11 +99,21 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         _num_rows = rows;
         _num_cols = cols;
         if (_print_csv && is_root()) std::cout << rows << ",";
-        // every locally owned shard reads its own row block, in chunks of <= 256 MiB
+        // Every locally owned shard takes its own row block straight from a read-only mapping of the
+        // file (no intermediate read buffer), in chunks of <= 1 GiB so that a single upload never
+        // exceeds 2^31 elements -- the reference's MPI_File_read count is an int (CPU_MPI_OMP.hpp:408).
         int total = 0, local = 0;
         lam_hip_num_shards(_ctx, &total, &local);
-        const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / (cols * sizeof(FloatingType)));
-        std::vector<FloatingType> buf(chunk_rows * cols);
+        const uint64_t file_bytes = 16 + rows * cols * sizeof(FloatingType);
+        void *map = mmap(nullptr, file_bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (map == MAP_FAILED) {
+            if (is_root()) fprintf(stderr, "Cannot map matrix file\n");
+            close(fd);
+            return false;
+        }
+        (void)madvise(map, file_bytes, MADV_SEQUENTIAL);
+        const FloatingType *data = reinterpret_cast<const FloatingType *>(static_cast<const char *>(map) + 16);
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (1ull << 30) / (cols * sizeof(FloatingType)));
         bool ok = true;
         for (int q = 0; q < total && ok; q++) {
             if (local != total && q != _rank) continue;
@@ -110,16 +121,10 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
             lam_hip_get_partition(_ctx, q, &r0, &nr);
             for (uint64_t r = r0; r < r0 + nr && ok; r += chunk_rows) {
                 const uint64_t n = std::min(chunk_rows, r0 + nr - r);
-                const uint64_t bytes = n * cols * sizeof(FloatingType);
-                uint64_t got = 0;
-                while (got < bytes) {
-                    ssize_t k = pread(fd, (char *)buf.data() + got, bytes - got, 16 + r * cols * sizeof(FloatingType) + got);
-                    if (k <= 0) { ok = false; break; }
-                    got += (uint64_t)k;
-                }
-                if (ok && lam_hip_upload_rows(_ctx, r, n, buf.data()) != 0) { report("upload_rows"); ok = false; }
+                if (lam_hip_upload_rows(_ctx, r, n, data + r * cols) != 0) { report("upload_rows"); ok = false; }
             }
         }
+        munmap(map, file_bytes);
         close(fd);
         if (!ok && is_root()) fprintf(stderr, "Failed to read matrix rows\n");
         return ok;
