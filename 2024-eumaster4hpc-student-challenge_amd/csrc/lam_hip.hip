@@ -295,6 +295,9 @@ int dispatch(lam_hip_ctx *c, F &&f)
 int set_dev(lam_hip_ctx *c, const ShardBase &s)
 {
     HIPCHK(c, hipSetDevice(s.dev));
+    // hipGetLastError() is only used to pick up launch failures right after a launch; drop whatever an
+    // earlier, already reported failure (possibly of another context) left in the thread's error slot
+    (void)hipGetLastError();
     return 0;
 }
 
@@ -315,7 +318,7 @@ PtrList plist_gather(lam_hip_ctx *c, bool second)
 
 void free_shard(ShardBase &s)
 {
-    (void)hipSetDevice(s.dev);
+    if (hipSetDevice(s.dev) != hipSuccess) { (void)hipGetLastError(); return; }   // never created on a real device
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
                     s.r_full, s.ap_gather};
     for (void *q : ptrs) if (q) (void)hipFree(q);

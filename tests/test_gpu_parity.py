@@ -408,3 +408,22 @@ def test_invalid_sizes_are_rejected(lam):
         lam.Solver(lam.F64, n_shards=1, device_ids=[99])
     with pytest.raises(lam.LamHipError):
         lam.Solver(7)                                  # unknown dtype
+
+
+def test_config3_shape_eight_shards_full_size(lam):
+    """BASELINE configs[2]: N=65536 fp64 row-sharded 8 ways (here 8 shards on one device, peer-store
+    exchange).  Size-independent property: the sharded run reproduces the single-shard run to rounding,
+    and its recursive residual equals the recomputed true residual."""
+    n = 65536
+    res = []
+    for shards in (1, 8):
+        with lam.Solver(lam.F64, n_shards=shards, device_ids=[0] * shards) as s:
+            s.generate_random_spd(n, 1234, 1e6)
+            s.generate_random_rhs(1235)
+            s.solve(25, 1e-30)
+            res.append((s.stats["rel_err"], s.true_residual(), s.solution()))
+            if shards == 8:
+                assert [s.partition(q) for q in range(8)] == [(q * 8192, 8192) for q in range(8)]
+    (e1, t1, x1), (e8, t8, x8) = res
+    assert abs(e8 / e1 - 1) < 1e-9 and abs(t8 / e8 - 1) < 1e-6 and abs(t1 / e1 - 1) < 1e-6
+    assert np.linalg.norm(x8 - x1) / np.linalg.norm(x1) < 1e-10
