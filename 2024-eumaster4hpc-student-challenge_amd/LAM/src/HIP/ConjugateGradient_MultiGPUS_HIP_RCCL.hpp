@@ -19,8 +19,9 @@ template <typename FloatingType>
 class ConjugateGradient_MultiGPUS_HIP_RCCL : public ConjugateGradient_HIP_base<FloatingType>
 {
   public:
-    ConjugateGradient_MultiGPUS_HIP_RCCL(int rank, int num_ranks, int device, const void *unique_id)
-        : _num_ranks(num_ranks), _device(device)
+    // bf16_storage (float instantiation only): keep the matrix in bf16, vectors and accumulation in fp32
+    ConjugateGradient_MultiGPUS_HIP_RCCL(int rank, int num_ranks, int device, const void *unique_id, bool bf16_storage = false)
+        : _num_ranks(num_ranks), _device(device), _bf16(bf16_storage && std::is_same<FloatingType, float>::value)
     {
         this->_rank = rank;
         this->_print_csv = true;
@@ -32,11 +33,12 @@ class ConjugateGradient_MultiGPUS_HIP_RCCL : public ConjugateGradient_HIP_base<F
   protected:
     bool create_context(lam_hip_ctx **out) override
     {
-        return lam_hip_create_rank(out, this->dtype(), _device, this->_rank, _num_ranks, _id) == 0;
+        return lam_hip_create_rank(out, _bf16 ? LAM_HIP_BF16 : this->dtype(), _device, this->_rank, _num_ranks, _id) == 0;
     }
 
   private:
     int _num_ranks, _device;
+    bool _bf16;
     char _id[LAM_HIP_UNIQUE_ID_BYTES];
 };
 

@@ -1163,9 +1163,18 @@ int lam_hip_gemv_only(lam_hip_ctx *c, int reps, double *sec)
             LAMCHK(set_dev(c, s));
             const uint64_t nrows_saved = s.nrows;
             if (c->opt_probe_rows > 0) s.nrows = std::min<uint64_t>(s.nrows, (uint64_t)c->opt_probe_rows);
-            int rc = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);  // warm-up
+            // with panel_lo/panel_hi set the probe times the split form the rank mode uses (own-slice
+            // panel, then the remaining columns accumulated on top)
+            const bool split = c->opt_panel_hi > c->opt_panel_lo;
+            const uint64_t lo = (uint64_t)c->opt_panel_lo, hi = (uint64_t)c->opt_panel_hi;
+            auto one = [&]() -> int {
+                if (!split) return I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);
+                int r1 = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, nullptr, 1, lo, hi);
+                return r1 != 0 ? r1 : I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr, 2, lo, hi);
+            };
+            int rc = one();  // warm-up
             if (rc == 0 && hipEventRecord(s.ev_g0[0], s.stream) != hipSuccess) rc = LAM_HIP_EHIP;
-            for (int i = 0; i < reps && rc == 0; i++) rc = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);
+            for (int i = 0; i < reps && rc == 0; i++) rc = one();
             if (rc == 0 && hipEventRecord(s.ev_g1[0], s.stream) != hipSuccess) rc = LAM_HIP_EHIP;
             s.nrows = nrows_saved;
             if (rc != 0) return rc == LAM_HIP_EHIP ? fail(c, rc, "hipEventRecord failed in gemv_only") : rc;

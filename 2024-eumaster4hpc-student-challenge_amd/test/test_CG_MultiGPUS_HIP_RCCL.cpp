@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 #include <unistd.h>
@@ -36,10 +37,24 @@ void usage(const char *exe)
     printf("  -s <int>        Generate matrix of size n x n\n");
     printf("  -r <seed>       with -s: seeded dense random SPD system instead of tridiag(1,2,1)\n");
     printf("  -c <float>      with -r: spread of the spectrum (default 1e4)\n");
+    printf("  -t <type>       f64 (default, what the reference drivers hard-code), f32, or bf16 (bf16 matrix\n");
+    printf("                  storage, fp32 vectors); files hold doubles for f64 and floats otherwise\n");
     printf("  -v              Verbose mode\n");
     printf("  -h              Show this help message\n");
 }
 }  // namespace
+
+struct Options {
+    const char *matrix_file = "io/matrix.bin", *rhs_file = "io/rhs.bin", *sol_file = "io/sol.bin";
+    int max_iters = 10000;
+    double rel_error = 1e-9, cond = 1e4;
+    size_t rows = 0;
+    long seed = -1;
+    bool verbose = false, mode_generate = false, mode_load = false, bf16_storage = false;
+};
+
+template <typename T>
+int run(const lam_bootstrap::Launch &L, const Options &o, int ndev);
 
 int main(int argc, char **argv)
 {
@@ -48,16 +63,18 @@ int main(int argc, char **argv)
         fprintf(stderr, "bootstrap failed: %s\n", lam_hip_last_error(nullptr));
         return 1;
     }
-    const char *matrix_file = "io/matrix.bin", *rhs_file = "io/rhs.bin", *sol_file = "io/sol.bin";
-    int max_iters = 10000;
-    double rel_error = 1e-9, cond = 1e4;
-    size_t rows = 0;
-    long seed = -1;
-    bool verbose = false, mode_generate = false, mode_load = false;
+    Options o;
+    const char *&matrix_file = o.matrix_file, *&rhs_file = o.rhs_file, *&sol_file = o.sol_file;
+    int &max_iters = o.max_iters;
+    double &rel_error = o.rel_error, &cond = o.cond;
+    size_t &rows = o.rows;
+    long &seed = o.seed;
+    bool &verbose = o.verbose, &mode_generate = o.mode_generate, &mode_load = o.mode_load;
     const bool root = L.rank == 0;
+    const char *precision = "f64";
 
     int opt;
-    while ((opt = getopt(argc, argv, "hvA:b:o:i:e:s:r:c:")) != -1) {
+    while ((opt = getopt(argc, argv, "hvA:b:o:i:e:s:r:c:t:")) != -1) {
         switch (opt) {
         case 'A':
         case 'b':
@@ -81,6 +98,7 @@ int main(int argc, char **argv)
             break;
         case 'r': seed = atol(optarg); break;
         case 'c': cond = atof(optarg); break;
+        case 't': precision = optarg; break;
         case 'v': verbose = true; break;
         case 'h':
             if (root) usage(argv[0]);
@@ -100,7 +118,30 @@ int main(int argc, char **argv)
         fprintf(stderr, "No GPU: %s\n", lam_hip_last_error(nullptr));
         return 1;
     }
-    LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<double> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id);
+    int rc;
+    if (!strcmp(precision, "f64")) rc = run<double>(L, o, ndev);
+    else if (!strcmp(precision, "f32")) rc = run<float>(L, o, ndev);
+    else if (!strcmp(precision, "bf16")) { o.bf16_storage = true; rc = run<float>(L, o, ndev); }
+    else {
+        if (root) fprintf(stderr, "Unknown precision '%s' (f64, f32, bf16)\n", precision);
+        return 1;
+    }
+    lam_bootstrap::finalize(L);
+    return rc;
+}
+
+// the reference drivers hard-code <double> (test_CG_CPU_MPI_OMP.cpp:46,132); the class template is
+// instantiated for float too, so the precision is a run-time choice here
+template <typename T>
+int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
+{
+    const char *matrix_file = o.matrix_file, *rhs_file = o.rhs_file, *sol_file = o.sol_file;
+    const int max_iters = o.max_iters;
+    const double rel_error = o.rel_error, cond = o.cond;
+    const size_t rows = o.rows;
+    const long seed = o.seed;
+    const bool verbose = o.verbose, mode_generate = o.mode_generate, root = L.rank == 0;
+    LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<T> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id, o.bf16_storage);
     cg.set_csv_output(!verbose);
     if (cg.context() == nullptr) return 1;      // creates the RCCL communicator (collective)
     lam_bootstrap::communicator_ready(L);
@@ -147,6 +188,5 @@ int main(int argc, char **argv)
     }
     if (verbose && root) printf("Finished successfully\n");
     if (root) std::cout << std::endl;
-    lam_bootstrap::finalize(L);
     return 0;
 }

@@ -145,3 +145,17 @@ def test_mpi_bootstrapped_driver_single_rank(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     f = _csv(r.stdout)
     assert f[0] == "4096" and int(f[7]) == 16 and abs(float(f[8]) / 0.000368282 - 1) < 1e-5
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 2e-4)])
+def test_getopt_driver_runtime_precision(tmp_path, prec, tol):
+    """-t f32 / bf16: the reference hard-codes <double>; here the class template's float instantiation
+    (and bf16 matrix storage) is a run-time choice.  Generate mode known answer: tridiag entries and
+    b = 1 are exact in every precision, so 15 iterations still give 1/(15 sqrt(8N)) to fp32 rounding."""
+    r = _run([RCCL_EXE, "-s", "4096", "-i", "15", "-t", prec, "-o", str(tmp_path / "sol.bin")])
+    assert r.returncode == 0, r.stderr
+    f = _csv(r.stdout)
+    assert int(f[7]) == 16 and abs(float(f[8]) / 0.000368282 - 1) < tol
+    x = np.fromfile(tmp_path / "sol.bin", dtype=np.float32, offset=16)
+    assert x.size == 4096 and np.all(np.isfinite(x))
+    assert _run([RCCL_EXE, "-s", "64", "-t", "fp8"]).returncode == 1
