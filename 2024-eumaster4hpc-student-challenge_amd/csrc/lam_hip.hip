@@ -64,7 +64,9 @@ struct ShardBase {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_p = nullptr;  // cross-shard ordering
     hipEvent_t ev_gathered = nullptr;                           // all-gather on comm_stream finished
     hipEvent_t ev_lag[kLag] = {};
-    hipEvent_t ev_g0[kLag] = {}, ev_g1[kLag] = {};              // gemv timing ring
+    hipEvent_t ev_g0[kLag] = {}, ev_g1[kLag] = {};              // gemv timing ring (whole GEMV, or its first panel)
+    hipEvent_t ev_g2[kLag] = {}, ev_g3[kLag] = {};              // second panel of a split GEMV
+    bool split_slot[kLag] = {};
 };
 
 }  // namespace
@@ -355,7 +357,8 @@ int create_common(lam_hip_ctx *c)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
         for (int i = 0; i < kLag; i++) {
             if (hipEventCreateWithFlags(&s.ev_lag[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreate(&s.ev_g0[i]) != hipSuccess || hipEventCreate(&s.ev_g1[i]) != hipSuccess)
+                hipEventCreate(&s.ev_g0[i]) != hipSuccess || hipEventCreate(&s.ev_g1[i]) != hipSuccess ||
+                hipEventCreate(&s.ev_g2[i]) != hipSuccess || hipEventCreate(&s.ev_g3[i]) != hipSuccess)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
         }
     }
@@ -609,16 +612,22 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             LAMCHK(set_dev(c, s));
             uint64_t lo, hi;
             cg_panel<I>(c, s, &lo, &hi);
-            HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+            s.split_slot[slot] = hi > lo;
             if (hi > lo) {
+                // the two panels are timed separately so that t_gemv is kernel time, not the wait in between
+                HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
                 LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, s.sc, 1, lo, hi));
+                HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
                 if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
+                HIPCHK(c, hipEventRecord(s.ev_g2[slot], s.stream));
                 LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi));
+                HIPCHK(c, hipEventRecord(s.ev_g3[slot], s.stream));
             } else {
                 if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
+                HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
                 LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+                HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
             }
-            HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
         }
         c->gather_pending = false;
         LAMCHK(reduce_step(c, false, true, true));
@@ -764,6 +773,8 @@ void lam_hip_destroy(lam_hip_ctx *c)
             if (s.ev_lag[i]) (void)hipEventDestroy(s.ev_lag[i]);
             if (s.ev_g0[i]) (void)hipEventDestroy(s.ev_g0[i]);
             if (s.ev_g1[i]) (void)hipEventDestroy(s.ev_g1[i]);
+            if (s.ev_g2[i]) (void)hipEventDestroy(s.ev_g2[i]);
+            if (s.ev_g3[i]) (void)hipEventDestroy(s.ev_g3[i]);
         }
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
@@ -1003,6 +1014,13 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     int gemv_samples = 0;
     int enq = 0;
     bool stopped = false;
+    auto harvest = [&](int slot) {   // GEMV device time of a finished iteration
+        float ms = 0.f, ms2 = 0.f;
+        if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) != hipSuccess) return;
+        if (s0.split_slot[slot] && hipEventElapsedTime(&ms2, s0.ev_g2[slot], s0.ev_g3[slot]) != hipSuccess) return;
+        gemv_ms += ms + ms2;
+        gemv_samples++;
+    };
     // already converged in an earlier call?
     LAMCHK(set_dev(c, s0));
     HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
@@ -1019,8 +1037,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             // number of (no-op) iterations and their collectives stay matched.
             LAMCHK(set_dev(c, s0));
             HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) == hipSuccess) { gemv_ms += ms; gemv_samples++; }
+            harvest(slot);
             if (((volatile int *)s0.host_flags)[1]) { stopped = true; break; }
         }
         LAMCHK(enqueue_iteration(c, k, rel_error, slot));
@@ -1032,11 +1049,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
     // harvest the GEMV timings still in the ring
-    for (int j = std::max(0, enq - kLag); j < enq; j++) {
-        float ms = 0.f;
-        const int slot = j % kLag;
-        if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) == hipSuccess) { gemv_ms += ms; gemv_samples++; }
-    }
+    for (int j = std::max(0, enq - kLag); j < enq; j++) harvest(j % kLag);
     LAMCHK(set_dev(c, s0));
     HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
     HIPCHK(c, hipStreamSynchronize(s0.stream));
