@@ -97,7 +97,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=65536, help="matrix order (default: BASELINE configs[2])")
+    # under torch.distributed.run use --order: the launcher's own parser treats "--n" as an ambiguous
+    # abbreviation of its --nnodes/--nproc-per-node/... options even after the script name
+    ap.add_argument("--n", "--order", dest="n", type=int, default=65536, help="matrix order (default: BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (N=32768) run")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
@@ -128,7 +130,7 @@ def main():
     also = None
     if rank == 0 and not use_dist and max(1, args.gpus) == 1 and not args.no_also and args.n != 32768:
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--n", "32768", "--steps", str(args.steps),
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--order", "32768", "--steps", str(args.steps),
                                 "--warmup", str(args.warmup), "--no-also", "--no-cpu-baseline"],
                                capture_output=True, text=True, timeout=900)
             d = json.loads(r.stdout.strip().splitlines()[-1])

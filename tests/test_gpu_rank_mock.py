@@ -57,3 +57,47 @@ def test_rank_mode_multi_rank_on_mock_rccl(mock_lib, P, n, mode, overlap, exchan
     assert out["gemv_vs_single"] < 1e-13
     base = n // P
     assert out["partition"] == [[q * base, base + (n % P if q == P - 1 else 0)] for q in range(P)]
+
+
+MOCK_MP = os.path.join(MOCK_DIR, "libmock_rccl_mp.so")
+
+
+@pytest.fixture(scope="module")
+def mock_mp_lib():
+    src = os.path.join(MOCK_DIR, "mock_rccl_mp.cpp")
+    if not os.path.exists(MOCK_MP) or os.path.getmtime(MOCK_MP) < os.path.getmtime(src):
+        # g++ and NOT linked against libamdhip64: the HIP symbols bind at first use to whatever runtime
+        # the process already holds (torch's, in the torchrun path) instead of dragging in a second one
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        src, "-o", MOCK_MP, "-lrt", "-lpthread"], check=True)
+    return MOCK_MP
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_bench_torchrun_path_end_to_end_on_mock_rccl(mock_mp_lib, nproc):
+    """The exact command line the driver uses for N > 1 GPUs -- torch.distributed.run, one process per
+    rank, gloo control plane, unique-id broadcast, both exchange modes, max-over-ranks timing, one JSON
+    line from rank 0 -- with every rank on GPU 0 and the multi-process mock in front of librccl."""
+    env = dict(os.environ, LD_PRELOAD=mock_mp_lib)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    port = 29700 + nproc + os.getpid() % 100
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "20",
+           "--warmup", "3", "--order", "8192"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                          # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == nproc and out["steps"] == 20 and out["scaling"] == "strong" and out["dtype"] == "f64"
+    assert out["metric"] == "cg_iterations_per_sec" and out["value"] > 0
+    assert set(out["exchange_modes"]) == {"allreduce_x2+allgather_p", "allgather_Ap"}
+    for m in out["exchange_modes"].values():
+        assert m["value"] > 0
+    # both exchanges solved the same problem: true residuals agree (different rounding only)
+    res = [m["rel_residual_true"] for m in out["exchange_modes"].values()]
+    assert abs(res[0] / res[1] - 1) < 1e-6
+    assert abs(out["rel_residual_true"] / out["rel_residual_recursive"] - 1) < 1e-6
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    assert abs(rf["algorithmic_bytes_per_launch"] - (8.0 * 8192 * 8192 / nproc + 8.0 * (8192 + 8192 / nproc))) < 1
