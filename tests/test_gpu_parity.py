@@ -427,3 +427,26 @@ def test_config3_shape_eight_shards_full_size(lam):
     (e1, t1, x1), (e8, t8, x8) = res
     assert abs(e8 / e1 - 1) < 1e-9 and abs(t8 / e8 - 1) < 1e-6 and abs(t1 / e1 - 1) < 1e-6
     assert np.linalg.norm(x8 - x1) / np.linalg.norm(x1) < 1e-10
+
+
+@pytest.mark.parametrize("dtype_name", ["F32", "BF16"])
+def test_config4_full_size_properties(lam, dtype_name):
+    """BASELINE configs[3]: N=131072 (fp32: 68.7 GB, bf16 storage: 34.4 GB; N^2 = 1.7e10 elements, so
+    every index is past 2^32).  Size-independent properties: GEMV linearity, and the recursive residual
+    of a short CG run equals the recomputed true residual to fp32 accuracy."""
+    n = 131072
+    with lam.Solver(getattr(lam, dtype_name)) as s:
+        s.generate_random_spd(n, 4321, 1e3)
+        s.generate_random_rhs(4322)
+        s.solve(12, 1e-30)
+        st, tr = s.stats, s.true_residual()
+        assert st["num_iters"] == 13
+        assert abs(tr / st["rel_err"] - 1) < 5e-3
+        rng = np.random.default_rng(1)
+        u, v = rng.uniform(-1, 1, n).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32)
+        yu, yv, yuv = s.gemv(u), s.gemv(v), s.gemv((2.0 * u - 3.0 * v).astype(np.float32))
+        assert np.max(np.abs(yuv - (2.0 * yu - 3.0 * yv))) <= 1e-4 * np.max(np.abs(yuv))
+        # the last row really is the last row (64-bit row offsets): A[n-1][n-1] is the only O(1) entry
+        e = np.zeros(n, dtype=np.float32); e[-1] = 1.0
+        col = s.gemv(e)
+        assert col[-1] > 0.9 and np.max(np.abs(col[:-1])) < 1e-4
