@@ -55,3 +55,15 @@ def test_product_does_not_reference_oracle():
                     if re.search(r"liboracle|pyoracle|cg_oracle|oracle/", t):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lam_hip.h must be consumable by a C compiler (the boundary is a C ABI, not C++)."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "lam_hip.h"\n'
+                   'int main(void) { lam_hip_stats st; lam_hip_ctx *c = 0; (void)st; (void)c;\n'
+                   '  return lam_hip_abi_version() == LAM_HIP_ABI_VERSION ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -450,3 +450,36 @@ def test_config4_full_size_properties(lam, dtype_name):
         e = np.zeros(n, dtype=np.float32); e[-1] = 1.0
         col = s.gemv(e)
         assert col[-1] > 0.9 and np.max(np.abs(col[:-1])) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# randomised sweep over sizes, shard counts and dtypes (seeded: the same 40 cases every run)
+# ------------------------------------------------------------------------------------------------
+def test_randomised_sizes_and_shards(lam, oracle):
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.integers(1, 1500))
+        P = int(rng.integers(1, min(n, 6) + 1))
+        dt_name = ["F64", "F64", "F32", "BF16"][int(rng.integers(0, 4))]
+        q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
+        A = (q * np.exp(1.5 * rng.uniform(-1, 1, n))) @ q.T
+        A = 0.5 * (A + A.T)
+        b = rng.uniform(-1, 1, n)
+        k = int(rng.integers(1, 12))
+        with lam.Solver(getattr(lam, dt_name), n_shards=P, device_ids=[0] * P) as s:
+            s.set_matrix(A)
+            s.set_rhs(b)
+            A_dev = s.download_rows(0, n).astype(np.float64)
+            s.solve(k, 1e-30)
+            x, st = s.solution().astype(np.float64), s.stats
+            y = s.gemv(b).astype(np.float64)
+            parts = [s.partition(r) for r in range(P)]
+        assert parts == [oracle.partition(n, P, r) for r in range(P)]
+        eps = 2.0 ** -52 if dt_name == "F64" else 2.0 ** -24
+        scale = np.abs(A_dev) @ np.abs(b)
+        assert np.max(np.abs(y - A_dev @ b) / np.maximum(scale, 1e-300)) <= 64 * eps, (case, n, P, dt_name)
+        x_ref, st_ref = oracle.cg_solve(A_dev, b, k, 1e-30)          # fp64 oracle on the matrix the device holds
+        assert st["num_iters"] == st_ref["num_iters"] == k + 1
+        tol = 1e-9 if dt_name == "F64" else 2e-3
+        assert abs(st["rel_err"] / st_ref["rel_err"] - 1) < tol, (case, n, P, dt_name, k)
+        assert np.linalg.norm(x - x_ref) <= tol * np.linalg.norm(x_ref), (case, n, P, dt_name, k)
