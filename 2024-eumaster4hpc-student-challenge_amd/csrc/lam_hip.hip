@@ -333,6 +333,20 @@ void free_shard(ShardBase &s)
     s.sc = nullptr; s.sc_host = nullptr;
 }
 
+// streams and events of one shard (device memory is released by free_shard)
+void release_handles(ShardBase &s)
+{
+    if (hipSetDevice(s.dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipEvent_t *evs[] = {&s.ev_a, &s.ev_b, &s.ev_p, &s.ev_gathered};
+    for (auto e : evs) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    for (int i = 0; i < kLag; i++) {
+        hipEvent_t *ring[] = {&s.ev_lag[i], &s.ev_g0[i], &s.ev_g1[i], &s.ev_g2[i], &s.ev_g3[i]};
+        for (auto e : ring) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    }
+    if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); s.comm_stream = nullptr; }
+    if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
+}
+
 int create_common(lam_hip_ctx *c)
 {
     int ndev = 0;
@@ -696,7 +710,7 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
         c->sh[q].dev = device_ids ? device_ids[q] : q % ndev;
     }
     int rc = create_common(c.get());
-    if (rc != 0) { for (auto &s : c->sh) free_shard(s); return rc; }
+    if (rc != 0) { for (auto &s : c->sh) { free_shard(s); release_handles(s); } return rc; }
     *out = c.release();
     return 0;
 }
@@ -735,19 +749,19 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     c->sh[0].index = rank;
     c->sh[0].dev = device_id;
     int rc = create_common(c.get());
-    if (rc != 0) { for (auto &s : c->sh) free_shard(s); return rc; }
+    if (rc != 0) { for (auto &s : c->sh) { free_shard(s); release_handles(s); } return rc; }
     if (c->rank_mode) {
         const double t0 = now_s();
         ncclUniqueId id;
         if (unique_id) memcpy(&id, unique_id, sizeof id);
         else if (ncclGetUniqueId(&id) != ncclSuccess) {
-            for (auto &s : c->sh) free_shard(s);
+            for (auto &s : c->sh) { free_shard(s); release_handles(s); }
             return fail(nullptr, LAM_HIP_ERCCL, "ncclGetUniqueId failed");
         }
         (void)hipSetDevice(device_id);
         ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
         if (r != ncclSuccess) {
-            for (auto &s : c->sh) free_shard(s);
+            for (auto &s : c->sh) { free_shard(s); release_handles(s); }
             return fail(nullptr, LAM_HIP_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));
         }
         c->t_comm_init = now_s() - t0;
@@ -766,17 +780,7 @@ void lam_hip_destroy(lam_hip_ctx *c)
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (auto &s : c->sh) {
         free_shard(s);
-        hipEvent_t evs[] = {s.ev_a, s.ev_b, s.ev_p, s.ev_gathered};
-        for (auto e : evs) if (e) (void)hipEventDestroy(e);
-        if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); }
-        for (int i = 0; i < kLag; i++) {
-            if (s.ev_lag[i]) (void)hipEventDestroy(s.ev_lag[i]);
-            if (s.ev_g0[i]) (void)hipEventDestroy(s.ev_g0[i]);
-            if (s.ev_g1[i]) (void)hipEventDestroy(s.ev_g1[i]);
-            if (s.ev_g2[i]) (void)hipEventDestroy(s.ev_g2[i]);
-            if (s.ev_g3[i]) (void)hipEventDestroy(s.ev_g3[i]);
-        }
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+        release_handles(s);
     }
     delete c;
 }
