@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     args = ap.parse_args()
 
+    # the host driver on these nodes only supports dmabuf IPC; RCCL across processes needs this
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
