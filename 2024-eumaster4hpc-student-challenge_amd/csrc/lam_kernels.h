@@ -105,6 +105,14 @@ template <> struct MatVec<__hip_bfloat16> {
     }
 };
 
+// non-temporal scalar load of one matrix element (bf16 goes through its 16-bit pattern)
+template <typename T> __device__ __forceinline__ T nt_load(const T *p) { return __builtin_nontemporal_load(p); }
+template <> __device__ __forceinline__ __hip_bfloat16 nt_load<__hip_bfloat16>(const __hip_bfloat16 *p)
+{
+    const unsigned short bits = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p));
+    return __builtin_bit_cast(__hip_bfloat16, bits);
+}
+
 // scalar widening of one matrix element to the vector type
 template <typename TV> __device__ __forceinline__ TV widen(double v) { return (TV)v; }
 template <typename TV> __device__ __forceinline__ TV widen(float v) { return (TV)v; }
@@ -515,7 +523,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
     }
 }
 
-// General path (any n, any alignment): one wave per row, scalar loads, p from global/L2.
+// General path (any n, any alignment): one wave per row, per-row alignment peel + 16-B loads, p from L2.
 template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)
 gemv_generic_kernel(GemvArgs<TA, TV> a)
@@ -529,8 +537,39 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
     if (row < a.nrows) {
         const TA *ar = a.A + row * a.n;
         TV acc = (TV)0;
-        for (int sg = 0; sg < a.nseg; sg++)
-            for (uint64_t c = a.seg_begin[sg] + lane; c < a.seg_end[sg]; c += 64) acc += widen<TV>(ar[c]) * a.p[c];
+        using MV = MatVec<TA>;
+        using avec_t = typename MV::vec_t;
+        constexpr int VEC = MV::N;
+        for (int sg = 0; sg < a.nseg; sg++) {
+            const uint64_t beg = a.seg_begin[sg], end = a.seg_end[sg];
+            // Rows of an odd-N matrix start at any element offset: peel scalar columns up to the next
+            // 16-byte boundary of THIS row, stream the aligned middle with 16-B non-temporal loads
+            // (p is read element-wise from L2: its alignment differs from the row's), finish scalar.
+            const uint64_t addr = reinterpret_cast<uint64_t>(ar + beg);
+            uint64_t peel = ((16 - (addr & 15)) & 15) / sizeof(TA);
+            if (peel > end - beg) peel = end - beg;
+            if ((uint64_t)lane < peel) acc += widen<TV>(ar[beg + lane]) * a.p[beg + lane];
+            const uint64_t mid = beg + peel;
+            const uint64_t nvec = (end - mid) / VEC;
+            uint64_t v = lane;
+#pragma unroll 1
+            for (; v + 3 * 64 < nvec; v += 4 * 64) {
+                avec_t av[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    av[u] = __builtin_nontemporal_load(reinterpret_cast<const avec_t *>(ar + mid) + v + u * 64);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) acc += (TV)MV::get(av[u], i) * a.p[mid + (v + u * 64) * VEC + i];
+            }
+            for (; v < nvec; v += 64) {
+                const avec_t av = *(reinterpret_cast<const avec_t *>(ar + mid) + v);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) acc += (TV)MV::get(av, i) * a.p[mid + v * VEC + i];
+            }
+            for (uint64_t c = mid + nvec * VEC + lane; c < end; c += 64) acc += widen<TV>(ar[c]) * a.p[c];
+        }
         acc = wave_sum(acc);
         if (lane == 0) {
             if (a.accumulate) acc += a.y[row];
