@@ -169,7 +169,7 @@ struct Impl {
     // rows per WORKGROUP of each variant (variants 9.. are the cooperative-row shape: R rows per workgroup)
     static int variant_rows_per_block(int v)
     {
-        static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 1, 2, 2, 4, 3,
+        static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 2, 2, 2, 4, 3,
                                                   /* 19-22: MFMA bf16 experiment (bf16 storage only) */ 8, 8, 16, 4};
         return rows[v];
     }
@@ -244,7 +244,7 @@ struct Impl {
             case 11: launch_coop<4>(c, grid, s.stream, a); break;
             case 12: launch_coop<8>(c, grid, s.stream, a); break;
             case 13: launch_coop<2, 4096, 8>(c, grid, s.stream, a); break;
-            case 14: launch_coop<1, 4096, 4, 8>(c, grid, s.stream, a); break;
+            case 14: launch_coop<2, 2048, 4, 4>(c, grid, s.stream, a); break;
             case 15: launch_coop<2, 8192, 8, 8>(c, grid, s.stream, a); break;
             case 16: launch_coop<2, 8192, 4, 8>(c, grid, s.stream, a); break;
             case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
