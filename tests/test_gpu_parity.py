@@ -483,3 +483,19 @@ def test_randomised_sizes_and_shards(lam, oracle):
         tol = 1e-9 if dt_name == "F64" else 2e-3
         assert abs(st["rel_err"] / st_ref["rel_err"] - 1) < tol, (case, n, P, dt_name, k)
         assert np.linalg.norm(x - x_ref) <= tol * np.linalg.norm(x_ref), (case, n, P, dt_name, k)
+
+
+def test_maximum_size_known_answer(lam):
+    """Edge case 'maximum sizes': N=180000 fp64 = 259 GB, 90 % of the 288 GB HBM3E of one MI355X (the
+    reference needed 8+ GPUs' worth of nodes for its N=180000 generate-mode runs,
+    /root/reference/TESTS/CPU_SCRIPTS/CPU_8_NODE_gen.sh:24-32).  Generate mode, 10 iterations: the printed
+    error must be the closed form 1/(k sqrt(8N)) = 8.33333e-05 (= 1/12000)."""
+    n, k = 180000, 10
+    with lam.Solver(lam.F64) as s:
+        s.generate_matrix(n)
+        s.generate_rhs()
+        s.solve(k, 1e-9)
+        st = s.stats
+    assert st["num_iters"] == k + 1
+    assert abs(st["rel_err"] * 12000.0 - 1.0) < 1e-5
+    assert st["gemv_bytes"] / st["t_gemv"] > 5.0e12      # still streaming near the roofline at this size
