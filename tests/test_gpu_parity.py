@@ -492,7 +492,12 @@ def test_maximum_size_known_answer(lam):
     error must be the closed form 1/(k sqrt(8N)) = 8.33333e-05 (= 1/12000)."""
     n, k = 180000, 10
     with lam.Solver(lam.F64) as s:
-        s.generate_matrix(n)
+        try:
+            s.generate_matrix(n)
+        except lam.LamHipError as e:
+            if e.code == -5:
+                pytest.skip("less than 259 GB of free HBM on this device")
+            raise
         s.generate_rhs()
         s.solve(k, 1e-9)
         st = s.stats
