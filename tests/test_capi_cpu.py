@@ -4,8 +4,6 @@ import ctypes as C
 import os
 import re
 
-import pytest
-
 from conftest import ROOT
 
 
