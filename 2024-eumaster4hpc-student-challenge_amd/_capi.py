@@ -87,6 +87,7 @@ def lib():
             "lam_hip_true_residual": ([vp, C.POINTER(C.c_double)], i32),
             "lam_hip_gemv": ([vp, vp, vp], i32),
             "lam_hip_gemv_only": ([vp, i32, C.POINTER(C.c_double)], i32),
+            "lam_hip_check_symmetry": ([vp, C.POINTER(C.c_double)], i32),
             "lam_hip_dot": ([vp, vp, vp, u64, C.POINTER(C.c_double)], i32),
             "lam_hip_axpby": ([vp, C.c_double, vp, C.c_double, vp, u64], i32),
             "lam_hip_set_option": ([vp, C.c_char_p, C.c_int64], i32),
@@ -333,6 +334,16 @@ class Solver:
         self._chk(self._L.lam_hip_axpby(self._h, alpha, x.ctypes.data_as(C.c_void_p), beta,
                                         y.ctypes.data_as(C.c_void_p), x.size))
         return y
+
+    def check_symmetry(self):
+        v = C.c_double()
+        self._chk(self._L.lam_hip_check_symmetry(self._h, C.byref(v)))
+        return v.value
+
+    def get_option(self, name):
+        v = C.c_int64()
+        self._chk(self._L.lam_hip_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_option(self, name, value):
         self._chk(self._L.lam_hip_set_option(self._h, name.encode(), value))

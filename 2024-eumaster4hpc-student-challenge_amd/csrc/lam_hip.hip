@@ -22,6 +22,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/lam_hip.h"
@@ -52,6 +53,9 @@ struct ShardBase {
     void *tmp = nullptr;         // n: scratch vector (gemv op input / residual)
     void *r_full = nullptr;      // n: replicated r (rank mode, gather-Ap exchange only)
     void *ap_gather = nullptr;   // nranks records [Ap slice | double]: gather-Ap exchange only
+    void *symv_rowpart = nullptr, *symv_colpart = nullptr;   // symmetric product (option "symmetric")
+    SymvTask *symv_tasks = nullptr;
+    int symv_ntasks = 0;
     double *part_gemv = nullptr; // [gemv_blocks]
     double *part_vec = nullptr;  // [vec_blocks]
     double *gather_a = nullptr;  // [kMaxShards] p.Ap partials of all shards (or the reduced scalar at [0])
@@ -91,8 +95,16 @@ struct lam_hip_ctx {
     int64_t opt_overlap = 1;       // rank mode: all-gather on its own stream under the own-slice GEMV panel
     int64_t opt_panel_lo = 0, opt_panel_hi = 0;  // testing: split the CG GEMV into [lo,hi) + the rest
     bool gather_pending = false;   // an all-gather of p is in flight on comm_stream
+    int64_t opt_symmetric = 0;     // single shard: read only the upper triangle (caller asserts A == A^T)
     int64_t opt_exchange = 0;      // rank mode: 0 = all-reduce x2 + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
+
+    // the symmetric product exists for one shard, fp64/fp32 storage, n a multiple of its column tile
+    uint64_t symv_tile() const { return 8ull * kBlock * (16 / esz_a()); }
+    bool symv_active() const
+    {
+        return opt_symmetric && !rank_mode && total_shards == 1 && dtype != LAM_HIP_BF16 && n > 0 && n % symv_tile() == 0;
+    }
 
     // gather-Ap needs equal slices and an 8-byte aligned tail for the double
     bool exchange1_ok() const
@@ -183,7 +195,16 @@ struct Impl {
         return sizeof(TA) == 2 ? 0 : 10;
     }
 
+    // number of p.Ap partials the product step of a CG iteration leaves in part_gemv
     static int gemv_grid(const lam_hip_ctx *c, uint64_t nrows)
+    {
+        if (nrows == 0) return 0;
+        if (c->symv_active()) return (int)(c->n / kSymvRows);     // symmetric product: one per 32-row block
+        return kernel_grid(c, nrows);
+    }
+
+    // workgroups of the general GEMV kernel (also used on its own by the residual check)
+    static int kernel_grid(const lam_hip_ctx *c, uint64_t nrows)
     {
         if (nrows == 0) return 0;
         const uint64_t rows_per_block = fast_ok(c) ? (uint64_t)variant_rows_per_block(variant(c)) : (uint64_t)kWaves;
@@ -197,6 +218,35 @@ struct Impl {
             hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, true, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
         else
             hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
+    }
+
+    // y = A p from the upper triangle only (lam_kernels.h, "Symmetric product")
+    static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
+    {
+        if constexpr (std::is_same<TA, TV>::value) {
+            const uint64_t n = c->n;
+            const uint32_t ntiles = (uint32_t)(n / SymvShape<TA>::TILE), nblk = (uint32_t)(n / kSymvRows);
+            if (s.symv_tasks == nullptr) {
+                std::vector<SymvTask> tasks;
+                for (uint32_t I = 0; I < nblk; I++)
+                    for (uint32_t j = (uint32_t)(((uint64_t)I * kSymvRows) / SymvShape<TA>::TILE); j < ntiles; j++) tasks.push_back({I, j});
+                HIPCHK(c, hipMalloc((void **)&s.symv_tasks, tasks.size() * sizeof(SymvTask)));
+                HIPCHK(c, hipMalloc(&s.symv_rowpart, (size_t)nblk * ntiles * kSymvRows * sizeof(TA)));
+                HIPCHK(c, hipMalloc(&s.symv_colpart, (size_t)nblk * n * sizeof(TA)));
+                HIPCHK(c, hipMemcpy(s.symv_tasks, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMemsetAsync(s.symv_colpart, 0, (size_t)nblk * n * sizeof(TA), s.stream));
+                s.symv_ntasks = (int)tasks.size();
+            }
+            hipLaunchKernelGGL((symv_task_kernel<TA>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
+                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, n, ntiles, sc);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL((symv_reduce_kernel<TA>), dim3(nblk), dim3(kBlock), 0, s.stream, (const TA *)s.symv_rowpart,
+                               (const TA *)s.symv_colpart, (const TA *)p, (TA *)y, partial, n, ntiles, sc);
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        } else {
+            return fail(c, LAM_HIP_EINVAL, "the symmetric product needs matrix and vector of one type");
+        }
     }
 
     // panel: 0 = whole GEMV; 1 = only columns [lo,hi); 2 = everything but [lo,hi), accumulated onto y
@@ -226,7 +276,7 @@ struct Impl {
             if (a.nseg == 0) return 0;
             if (a.nseg == 1) { a.seg_begin[1] = a.seg_end[1] = 0; }
         }
-        const int grid = gemv_grid(c, s.nrows);
+        const int grid = kernel_grid(c, s.nrows);
         if (fast_ok(c)) {
             switch (variant(c)) {
             default:
@@ -322,9 +372,11 @@ void free_shard(ShardBase &s)
 {
     if (hipSetDevice(s.dev) != hipSuccess) { (void)hipGetLastError(); return; }   // never created on a real device
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
-                    s.r_full, s.ap_gather};
+                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    s.r_full = s.ap_gather = nullptr;
+    s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = nullptr;
+    s.symv_tasks = nullptr;
+    s.symv_ntasks = 0;
     if (s.sc_host) (void)hipHostFree(s.sc_host);
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     s.host_flags = nullptr;
@@ -626,6 +678,13 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             LAMCHK(set_dev(c, s));
             uint64_t lo, hi;
             cg_panel<I>(c, s, &lo, &hi);
+            if (c->symv_active()) {
+                s.split_slot[slot] = false;
+                HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+                LAMCHK(I::launch_symv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+                HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+                continue;
+            }
             s.split_slot[slot] = hi > lo;
             if (hi > lo) {
                 // the two panels are timed separately so that t_gemv is kernel time, not the wait in between
@@ -1141,7 +1200,17 @@ int lam_hip_gemv(lam_hip_ctx *c, const void *x_host, void *y_host)
         LAMCHK(set_dev(c, s));
         HIPCHK(c, hipMemcpyAsync(s.tmp, x_host, c->n * ev, hipMemcpyHostToDevice, s.stream));
     }
-    LAMCHK(gemv_tmp(c));
+    if (c->symv_active()) {
+        LAMCHK(dispatch(c, [&](auto impl) -> int {
+            using I = decltype(impl);
+            using TV = typename ImplTraits<I>::TV;
+            ShardBase &s = c->sh[0];
+            LAMCHK(set_dev(c, s));
+            return I::launch_symv(c, s, (const TV *)s.tmp, (TV *)s.Ap, nullptr, nullptr);
+        }));
+    } else {
+        LAMCHK(gemv_tmp(c));
+    }
     c->cg_ready = false;  // Ap was overwritten
     if (c->rank_mode) {
         ShardBase &s = c->sh[0];
@@ -1185,6 +1254,7 @@ int lam_hip_gemv_only(lam_hip_ctx *c, int reps, double *sec)
             const bool split = c->opt_panel_hi > c->opt_panel_lo;
             const uint64_t lo = (uint64_t)c->opt_panel_lo, hi = (uint64_t)c->opt_panel_hi;
             auto one = [&]() -> int {
+                if (c->symv_active()) return I::launch_symv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, getenv("LAM_PROBE_SC") ? s.sc : nullptr);
                 if (!split) return I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);
                 int r1 = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, nullptr, 1, lo, hi);
                 return r1 != 0 ? r1 : I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr, 2, lo, hi);
@@ -1271,6 +1341,37 @@ int lam_hip_true_residual(lam_hip_ctx *c, double *rel_res)
     return 0;
 }
 
+int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
+{
+    if (!c || !max_abs_asymmetry) return LAM_HIP_EINVAL;
+    if (!c->have_matrix) return fail(c, LAM_HIP_ESTATE, "matrix not set");
+    if (c->rank_mode || c->total_shards != 1) return fail(c, LAM_HIP_EINVAL, "symmetry check needs the whole matrix on one shard");
+    return dispatch(c, [&](auto impl) -> int {
+        using TA = typename ImplTraits<decltype(impl)>::TA;
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const int grid = 2048;
+        double *out = nullptr;
+        HIPCHK(c, hipMalloc((void **)&out, sizeof(double) * grid));
+        std::vector<double> h(grid);
+        if constexpr (sizeof(TA) == 2) {
+            (void)hipFree(out);
+            return fail(c, LAM_HIP_EINVAL, "symmetry check is implemented for fp64/fp32 storage");
+        } else {
+            hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->n, out);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(h.data(), out, sizeof(double) * grid, hipMemcpyDeviceToHost, s.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+            (void)hipFree(out);
+            if (e != hipSuccess) return fail(c, LAM_HIP_EHIP, "symmetry check: %s", hipGetErrorString(e));
+            double m = 0.0;
+            for (double v : h) m = std::max(m, v);
+            *max_abs_asymmetry = m;
+            return 0;
+        }
+    });
+}
+
 int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t n, double *result)
 {
     if (!c || !x_host || !y_host || !result) return LAM_HIP_EINVAL;
@@ -1339,6 +1440,7 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
     else if (!strcmp(name, "overlap")) c->opt_overlap = value;
     else if (!strcmp(name, "exchange")) { c->opt_exchange = value; c->cg_ready = false; }
+    else if (!strcmp(name, "symmetric")) c->opt_symmetric = value;
     else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
     else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;
     else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
@@ -1357,6 +1459,8 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "probe_rows")) *value = c->opt_probe_rows;
     else if (!strcmp(name, "overlap")) *value = c->opt_overlap;
     else if (!strcmp(name, "exchange")) *value = c->opt_exchange;
+    else if (!strcmp(name, "symmetric")) *value = c->opt_symmetric;
+    else if (!strcmp(name, "symmetric_effective")) *value = c->symv_active() ? 1 : 0;
     else if (!strcmp(name, "exchange_effective")) *value = c->exchange1_ok() ? 1 : 0;
     else if (!strcmp(name, "panel_lo")) *value = c->opt_panel_lo;
     else if (!strcmp(name, "panel_hi")) *value = c->opt_panel_hi;

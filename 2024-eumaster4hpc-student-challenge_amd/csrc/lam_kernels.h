@@ -523,6 +523,167 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Symmetric product (option "symmetric", single shard): y = A p reading only the UPPER triangle.
+// CG needs A symmetric positive definite, so A[i][j] (j > i) can serve both y_i += A_ij p_j and
+// y_j += A_ij p_i: 18.4 GB per product instead of 34.4 GB at N=65536 fp64 -- the only way past the
+// HBM roofline of the plain GEMV.  Two passes:
+//   symv_task_kernel    one workgroup per task = 32 rows x 8 super-steps of columns (a super-step is
+//                       the 4 KiB the 4 waves read contiguously per row), for the column tiles at or
+//                       right of the diagonal.  A lane keeps 32 row partials (its columns x 32 rows) in
+//                       registers across the tile and one column partial per owned column across the
+//                       32 rows, flushed once per super-step to colpart[I][c]; elements on or left of
+//                       the diagonal inside the diagonal block are masked (diagonal counted once).
+//   symv_reduce_kernel  y[i] = sum_j rowpart[I][j][i%32] + sum_{I'<=I} colpart[I'][i], fixed order
+//                       (deterministic), plus the workgroup's partial of p.y for the CG.
+// The caller asserts symmetry (lam_hip_check_symmetry measures it).  n must be a multiple of the tile.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSymvRows = 32;
+template <typename T> struct SymvShape {
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int SS = kBlock * VEC;          // columns per super-step
+    static constexpr int TILE = 8 * SS;              // columns per task
+};
+struct SymvTask { uint32_t I, j; };
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks,
+                 T *__restrict__ rowpart, T *__restrict__ colpart, uint64_t n, uint32_t ntiles, const CgScalars *sc)
+{
+    using SH = SymvShape<T>;
+    using MV = MatVec<T>;
+    using vec_t = typename MV::vec_t;
+    constexpr int VEC = SH::VEC, RB = kSymvRows;
+    __shared__ T s_pr[RB];
+    __shared__ T s_red[RB][kWaves];
+    if (sc != nullptr && sc->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SymvTask t = tasks[blockIdx.x];
+    const uint64_t r0 = (uint64_t)t.I * RB;
+    if (tid < RB) s_pr[tid] = p[r0 + tid];
+    __syncthreads();
+    const uint32_t cw = ((uint32_t)wave * 64 + (uint32_t)lane) * VEC;
+    T racc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) racc[r] = (T)0;
+
+    const uint64_t tile0 = (uint64_t)t.j * SH::TILE;
+    const T *Arow = A + r0 * n;
+    for (int ss = 0; ss < SH::TILE / SH::SS; ss++) {
+        const uint64_t c_ss = tile0 + (uint64_t)ss * SH::SS;
+        if (c_ss + SH::SS <= r0) continue;                     // entirely in the lower triangle
+        const uint64_t c = c_ss + cw;                          // this lane's VEC columns
+        const vec_t pc = *reinterpret_cast<const vec_t *>(p + c);
+        T cacc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) cacc[i] = (T)0;
+        const bool masked = c_ss < r0 + RB;                    // the super-step touches the diagonal block
+#pragma unroll
+        for (int sub = 0; sub < RB / 8; sub++) {
+            vec_t a[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                a[k] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Arow + (uint64_t)(sub * 8 + k) * n + c));
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = sub * 8 + k;
+                const T pr = s_pr[r];
+                if (!masked) {
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) {
+                        racc[r] += a[k][i] * pc[i];
+                        cacc[i] += a[k][i] * pr;
+                    }
+                } else {
+                    const uint64_t row = r0 + r;               // (row, col): col > row both, col == row once
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) {
+                        if (c + i >= row) racc[r] += a[k][i] * pc[i];
+                        if (c + i > row) cacc[i] += a[k][i] * pr;
+                    }
+                }
+            }
+        }
+        vec_t out;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) out[i] = cacc[i];
+        *reinterpret_cast<vec_t *>(colpart + (uint64_t)t.I * n + c) = out;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        const T sum = wave_sum(racc[r]);
+        if (lane == 0) s_red[r][wave] = sum;
+    }
+    __syncthreads();
+    if (tid < RB) {
+        T v = s_red[tid][0];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) v += s_red[tid][w];
+        rowpart[((uint64_t)t.I * ntiles + t.j) * RB + tid] = v;
+    }
+}
+
+// one workgroup per row block: thread (cx, iy) sums colpart[I'][i] for I' = iy, iy+8, ... <= I
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const T *__restrict__ p, T *__restrict__ y,
+                   double *__restrict__ partial, uint64_t n, uint32_t ntiles, const CgScalars *sc)
+{
+    constexpr int RB = kSymvRows;
+    __shared__ T s[kBlock / RB][RB];
+    __shared__ double s_dot[RB];
+    if (sc != nullptr && sc->stop) return;
+    const int cx = threadIdx.x % RB, iy = threadIdx.x / RB;
+    const uint64_t I = blockIdx.x, i = I * RB + cx;
+    T acc = (T)0;
+    for (uint64_t Ip = iy; Ip <= I; Ip += kBlock / RB) acc += colpart[Ip * n + i];
+    s[iy][cx] = acc;
+    __syncthreads();
+    if (iy == 0) {
+        T t = (T)0;
+#pragma unroll
+        for (int k = 0; k < kBlock / RB; k++) t += s[k][cx];
+        const uint32_t jd = (uint32_t)((I * RB) / SymvShape<T>::TILE);
+        for (uint32_t j = jd; j < ntiles; j++) t += rowpart[(I * ntiles + j) * RB + cx];
+        y[i] = t;
+        s_dot[cx] = (double)t * (double)p[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && partial != nullptr) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < RB; k++) d += s_dot[k];
+        partial[blockIdx.x] = d;
+    }
+}
+
+// max |A[i][j] - A[j][i]| over the local matrix (single shard), per-workgroup maxima in out[]
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+asymmetry_kernel(const T *__restrict__ A, uint64_t n, double *__restrict__ out)
+{
+    __shared__ double s_max[kWaves];
+    double m = 0.0;
+    const uint64_t total = n * n;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t i = idx / n, j = idx % n;
+        if (j > i) {
+            const double d = fabs((double)A[idx] - (double)A[j * n + i]);
+            m = d > m ? d : m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_max[0];
+        for (int w = 1; w < kWaves; w++) t = s_max[w] > t ? s_max[w] : t;
+        out[blockIdx.x] = t;
+    }
+}
+
 // General path (any n, any alignment): one wave per row, per-row alignment peel + 16-B loads, p from L2.
 template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)

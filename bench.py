@@ -77,10 +77,14 @@ def cpu_baseline(sample_n, iters):
             "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
 
 
-def run_config(lam, make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6):
+def run_config(lam, make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False):
     s = make_solver()
     s.generate_random_spd(n, seed, cond)
     s.generate_random_rhs(seed + 1)
+    if symmetric:
+        s.set_option("symmetric", 1)
+        if s.get_option("symmetric_effective") != 1:
+            raise SystemExit("option 'symmetric' is not available for this configuration")
     s.cg_init()
     if warmup > 0:
         s.cg_iterate(warmup, 0.0)
@@ -101,7 +105,9 @@ def main():
     # abbreviation of its --nnodes/--nproc-per-node/... options even after the script name
     ap.add_argument("--n", "--order", dest="n", type=int, default=65536, help="matrix order (default: BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (N=32768) run")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (N=32768) and symmetric-option runs")
+    ap.add_argument("--symmetric", action="store_true",
+                    help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     args = ap.parse_args()
@@ -142,6 +148,22 @@ def main():
         except Exception as e:   # noqa: BLE001
             sys.stderr.write(f"[bench] configs[1] side run failed: {e}\n")
 
+    # Opt-in "symmetric" product (reads only the upper triangle; 1 GPU), reported beside the headline,
+    # never as it: own process for the same reason as above.
+    sym = None
+    if rank == 0 and not use_dist and max(1, args.gpus) == 1 and not args.no_also and not args.symmetric:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--order", str(args.n), "--steps", str(args.steps),
+                                "--warmup", str(args.warmup), "--no-also", "--no-cpu-baseline", "--symmetric"],
+                               capture_output=True, text=True, timeout=900)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            sym = {"what": "lam_hip_set_option('symmetric', 1): the product reads only the upper triangle of the SPD matrix "
+                           "(two-pass, deterministic); same problem, own process; NOT the headline (different algorithm, "
+                           "single GPU only)", "value": d["value"], "ms_per_step": d["ms_per_step"],
+                   "product_ms": d["gemv_ms"], "rel_residual_true": d["rel_residual_true"]}
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write(f"[bench] symmetric-option side run failed: {e}\n")
+
     dist = None
     if use_dist:
         # torch.distributed is control plane only (rendezvous, barrier, max over ranks); the data
@@ -178,7 +200,7 @@ def main():
         parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores"
 
     n = args.n
-    s, st, dt = run_config(lam, make_solver, n, args.warmup, args.steps, barrier)
+    s, st, dt = run_config(lam, make_solver, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
 
     def max_over_ranks(dt_, st_):
         if dist is None:
@@ -261,6 +283,12 @@ def main():
 
     if also is not None:
         out["also"] = also
+    if sym is not None:
+        sym["speedup_vs_headline"] = sym["value"] / out["value"]
+        out["symmetric_option"] = sym
+    if args.symmetric:
+        out["config"]["workload"] += "; option symmetric=1 (upper-triangle product)"
+        out["roofline"] = None     # the GEMV roofline does not describe this algorithm
     if rank == 0 and n_gpus == 1 and world == 1:
         if cb is not None:
             # same unit as `value`, scaled to the workload's N (bytes per iteration scale with N^2)

@@ -172,6 +172,10 @@ int lam_hip_dot(lam_hip_ctx *ctx, const void *x_host, const void *y_host, uint64
 int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double beta, void *y_host,
                   uint64_t n);
 
+/* max |A[i][j] - A[j][i]| of the matrix held by a single-shard context (fp64/fp32 storage): lets a caller
+ * verify the precondition of option "symmetric".  No reference counterpart. */
+int lam_hip_check_symmetry(lam_hip_ctx *ctx, double *max_abs_asymmetry);
+
 /* ---- options --------------------------------------------------------------------------------- */
 /* name/value pairs; unknown names -> LAM_HIP_EINVAL.
  *   "exchange"      rank mode only.  0 (default): per iteration ncclAllReduce(p.Ap), ncclAllReduce(r.r),
@@ -180,6 +184,11 @@ int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double bet
  *                   updated redundantly (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505); needs
  *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  Re-run cg_init/solve
  *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts.
+ *   "symmetric"     single shard, fp64/fp32, N a multiple of 4096 (fp64) / 8192 (fp32): 1 = the matrix-vector
+ *                   product reads only the upper triangle (A must equal its transpose, which CG requires
+ *                   anyway; lam_hip_check_symmetry verifies it) -- about half the HBM traffic per iteration.
+ *                   0 (default) = the reference's general row-partitioned GEMV.  "symmetric_effective" tells
+ *                   whether the current context can use it.
  *   "overlap"       rank mode, exchange 0: 1 (default) puts the all-gather of p on a second stream under the
  *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.
  *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype; 0..22 = tuning shapes

@@ -504,3 +504,56 @@ def test_maximum_size_known_answer(lam):
     assert st["num_iters"] == k + 1
     assert abs(st["rel_err"] * 12000.0 - 1.0) < 1e-5
     assert st["gemv_bytes"] / st["t_gemv"] > 5.0e12      # still streaming near the roofline at this size
+
+
+# ------------------------------------------------------------------------------------------------
+# option "symmetric": the product reads only the upper triangle (precondition A == A^T)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype_name,n", [("F64", 4096), ("F64", 12288), ("F32", 8192), ("F32", 16384)])
+def test_symmetric_product_matches_general_gemv(lam, dtype_name, n):
+    eps = 2.0 ** -52 if dtype_name == "F64" else 2.0 ** -24
+    x = np.random.default_rng(n).uniform(-1, 1, n)
+    with lam.Solver(getattr(lam, dtype_name)) as s:
+        s.generate_random_spd(n, 31, 50.0)
+        assert s.check_symmetry() == 0.0
+        y0 = s.gemv(x).astype(np.float64)
+        s.set_option("symmetric", 1)
+        assert s.get_option("symmetric_effective") == 1
+        y1 = s.gemv(x).astype(np.float64)
+        A = s.download_rows(0, n).astype(np.float64) if n <= 4096 else None
+    if A is not None:
+        scale = np.abs(A) @ np.abs(x)
+        assert np.max(np.abs(y1 - A @ x) / scale) <= 64 * eps
+    assert np.max(np.abs(y1 - y0)) <= 64 * eps * np.max(np.abs(y0)) * 4
+
+
+def test_symmetric_cg_matches_general_cg(lam):
+    n = 8192
+    res = []
+    for sym in (0, 1):
+        with lam.Solver(lam.F64) as s:
+            s.generate_random_spd(n, 5, 1e3)
+            s.generate_random_rhs(6)
+            s.set_option("symmetric", sym)
+            conv = s.solve(2000, 1e-10)
+            res.append((conv, s.stats["num_iters"], s.solution(), s.true_residual()))   # true residual: general GEMV
+    (c0, k0, x0, t0), (c1, k1, x1, t1) = res
+    assert c0 and c1 and abs(k1 - k0) <= max(3, 0.02 * k0)
+    assert t1 <= 2e-10 and np.linalg.norm(x1 - x0) / np.linalg.norm(x0) < 1e-8
+
+
+def test_symmetric_option_preconditions(lam):
+    with lam.Solver(lam.F64) as s:
+        s.generate_random_spd(4100, 5, 10.0)           # not a multiple of the tile: option has no effect
+        s.set_option("symmetric", 1)
+        assert s.get_option("symmetric_effective") == 0
+        s.generate_random_spd(4096, 5, 10.0)
+        assert s.get_option("symmetric_effective") == 1
+        rows = s.download_rows(7, 1)
+        rows[0, 100] += 0.25                            # break the symmetry in one entry
+        s.upload_rows(7, rows)
+        assert abs(s.check_symmetry() - 0.25) < 1e-12
+    with lam.Solver(lam.F64, n_shards=2, device_ids=[0, 0]) as s:
+        s.generate_random_spd(4096, 5, 10.0)
+        s.set_option("symmetric", 1)
+        assert s.get_option("symmetric_effective") == 0   # single shard only
