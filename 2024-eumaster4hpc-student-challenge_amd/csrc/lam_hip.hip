@@ -1254,7 +1254,7 @@ int lam_hip_gemv_only(lam_hip_ctx *c, int reps, double *sec)
             const bool split = c->opt_panel_hi > c->opt_panel_lo;
             const uint64_t lo = (uint64_t)c->opt_panel_lo, hi = (uint64_t)c->opt_panel_hi;
             auto one = [&]() -> int {
-                if (c->symv_active()) return I::launch_symv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, getenv("LAM_PROBE_SC") ? s.sc : nullptr);
+                if (c->symv_active()) return I::launch_symv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);
                 if (!split) return I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr);
                 int r1 = I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, nullptr, 1, lo, hi);
                 return r1 != 0 ? r1 : I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, nullptr, 2, lo, hi);
