@@ -61,7 +61,7 @@ def cpu_baseline(sample_n, iters):
             ni = int(f[6])
             t_iter = float(f[5]) * ni * ni / iters
             t_gemv = float(f[4]) * ni * ni / iters
-            return {"value": 1.0 / t_iter, "unit": "cg_iterations/s", "cores": int(f[2]), "kind": "reference",
+            return {"value": 1.0 / t_iter, "unit": "iterations/s", "cores": int(f[2]), "kind": "reference",
                     "sample": f"oracle/_ref/test_CPU_MPI_OMP.out -s {sample_n} -i {iters} (generate mode, fp64, "
                               f"1 MPI rank x {f[2]} OpenMP threads; {sample_n}x{sample_n} matrix = "
                               f"{8.0 * sample_n * sample_n / 1e9:.1f} GB/iter)",
@@ -72,7 +72,7 @@ def cpu_baseline(sample_n, iters):
     from oracle import pyoracle
     st = pyoracle.cpu_baseline(sample_n, iters, cores)
     t_iter = st["t_total"] / iters
-    return {"value": 1.0 / t_iter, "unit": "cg_iterations/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / t_iter, "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": f"oracle port (cg_oracle.c, OpenMP x{cores}), generate mode N={sample_n} fp64, {iters} iterations",
             "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
 
