@@ -7,9 +7,12 @@
 //   gemv_tile_kernel -> [reduce p.Ap across shards] -> update_xr_kernel -> [reduce r.r across
 //   shards] -> update_p_kernel (stores the new p slice into every replica of p) -> [all-gather p]
 // "Across shards" is (a) nothing for one shard, (b) direct peer stores + cross-stream events when
-// one process drives several shards (xGMI point-to-point), (c) RCCL ncclAllReduce / ncclAllGather
-// when there is one process per GPU.  Scalars stay on the device; the host only polls a stop
-// flag with a lag of kLag iterations, so the queue never drains.
+// one process drives several shards (xGMI point-to-point), (c) RCCL when there is one process per
+// GPU: ncclAllReduce x2 + ncclAllGather(p) on a second stream under the own-slice GEMV panel
+// (exchange 0), or one ncclAllGather of [Ap slice | p.Ap partial] with full-length r/p per rank
+// (exchange 1).  Scalars stay on the device; the host only polls a stop flag with a lag of kLag
+// iterations, so the queue never drains.  Option "symmetric" (one shard) replaces the GEMV by the
+// two-pass upper-triangle product.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 

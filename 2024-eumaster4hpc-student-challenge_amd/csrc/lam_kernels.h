@@ -7,7 +7,7 @@
 //
 // Design:
 //   * one CG iteration = 3 launches on a shard:
-//       gemv_tile_kernel   Ap_loc = A_loc p          (+ per-block partials of p.Ap)
+//       gemv_coop_kernel   Ap_loc = A_loc p          (+ per-workgroup partials of p.Ap)
 //       update_xr_kernel   alpha = rr/(p.Ap); x += alpha p; r -= alpha Ap   (+ partials of r.r)
 //       update_p_kernel    rr' = r.r; beta = rr'/rr; stop test; p_slice = r + beta p  (stored into
 //                          every shard's replicated p)
@@ -15,11 +15,16 @@
 //     (CgScalars); the host never has to read a scalar to enqueue the next iteration.
 //   * all reductions are two-stage and fixed-order (no floating-point atomics): results are
 //     bit-reproducible run to run and identical on every shard.
-//   * GEMV is HBM-bound (0.25 flop/B in fp64): each wave streams R matrix rows with 16-byte
-//     non-temporal loads (1 KiB per wave instruction), the matching tile of p is staged once per
-//     workgroup in LDS and shared by 4 waves x R rows, lane partials are combined with wave64
-//     shuffles.  Tiles are visited in a per-workgroup rotated order so that concurrently running
-//     workgroups do not all sit at the same column offset of a power-of-two row pitch.
+//   * GEMV is HBM-bound (0.25 flop/B in fp64).  Production shape (gemv_coop_kernel): the 4 waves of a
+//     workgroup stream the same 2 matrix rows with 16-byte non-temporal loads, 4 KiB contiguous per row
+//     per super-step; the matching 4096-column tile of p is staged once per workgroup in LDS; lane
+//     partials are combined with wave64 shuffles and across waves through LDS.  gemv_tile_kernel (one
+//     group of R rows per wave) is the production shape for bf16 storage and carries the tuning
+//     variants; gemv_generic_kernel handles any N / alignment; gemv_mfma_bf16_kernel is the MFMA
+//     experiment (slower, kept for the record).  A launch can cover one or two column panels and
+//     accumulate, which is how the rank mode overlaps the all-gather of p with its own-slice panel.
+//   * the *_full_kernel pair implements the single-collective exchange (all-gather of Ap) of the rank
+//     mode; symv_*_kernel implement the opt-in symmetric product (upper triangle only).
 #pragma once
 
 #include <hip/hip_runtime.h>
