@@ -38,6 +38,24 @@
 namespace LAM
 {
 
+// Header of a matrix / vector file (random_spd_system.cpp:105-121: two 64-bit words, rows and cols).
+// The reference's own writers store an `int` with sizeof(size_t) -- cols in ConjugateGradient_CPU_OMP.hpp:
+// 206-210, BOTH words in ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:754-757 -- which leaves stack garbage
+// in the upper 32 bits.  One rule for every loader: take the two words as they are if the file is long
+// enough for them, otherwise their low 32 bits if THOSE fit the file, otherwise the file is bad.
+inline bool parse_bin_header(const uint64_t hdr[2], uint64_t file_bytes, uint64_t elem_bytes, uint64_t *rows, uint64_t *cols)
+{
+    auto fits = [&](uint64_t r, uint64_t c) {
+        if (r == 0 || c == 0 || file_bytes < 16) return false;
+        const unsigned __int128 need = (unsigned __int128)r * c * elem_bytes;
+        return need <= (unsigned __int128)(file_bytes - 16);
+    };
+    if (fits(hdr[0], hdr[1])) { *rows = hdr[0]; *cols = hdr[1]; return true; }
+    const uint64_t r = hdr[0] & 0xffffffffull, c = hdr[1] & 0xffffffffull;
+    if (fits(r, c)) { *rows = r; *cols = c; return true; }
+    return false;
+}
+
 template <typename FloatingType>
 class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
 {
@@ -77,21 +95,20 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
             if (is_root()) fprintf(stderr, "Cannot open output file\n");   // the reference's wording
             return false;
         }
-        uint64_t hdr[2];
-        if (pread(fd, hdr, sizeof hdr, 0) != (ssize_t)sizeof hdr) {
+        uint64_t hdr[2], rows = 0, cols = 0;
+        struct stat sb;
+        if (pread(fd, hdr, sizeof hdr, 0) != (ssize_t)sizeof hdr || fstat(fd, &sb) != 0) {
             if (is_root()) fprintf(stderr, "Cannot read matrix header\n");
             close(fd);
             return false;
         }
-        const uint64_t rows = hdr[0], cols = hdr[1];
-        if (rows != cols) {
-            if (is_root()) fprintf(stderr, "Matrix has to be square\n");
+        if (!parse_bin_header(hdr, (uint64_t)sb.st_size, sizeof(FloatingType), &rows, &cols)) {
+            if (is_root()) fprintf(stderr, "Matrix file is shorter than its header says\n");
             close(fd);
             return false;
         }
-        struct stat sb;
-        if (fstat(fd, &sb) == 0 && (uint64_t)sb.st_size < 16 + rows * cols * sizeof(FloatingType)) {
-            if (is_root()) fprintf(stderr, "Matrix file is shorter than its header says\n");
+        if (rows != cols) {
+            if (is_root()) fprintf(stderr, "Matrix has to be square\n");
             close(fd);
             return false;
         }
@@ -126,6 +143,8 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         }
         munmap(map, file_bytes);
         close(fd);
+        // a rank whose block failed must not leave the others waiting in the solve's first collective
+        ok = agree(ok);
         if (!ok && is_root()) fprintf(stderr, "Failed to read matrix rows\n");
         return ok;
     }
@@ -138,24 +157,29 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
             if (is_root()) fprintf(stderr, "Cannot open output file\n");
             return false;
         }
-        uint64_t hdr[2] = {0, 0};
-        if (fread(hdr, sizeof(uint64_t), 2, file) != 2) { fclose(file); return false; }
-        if ((hdr[1] & 0xffffffffull) != 1) {
+        uint64_t hdr[2] = {0, 0}, rows = 0, cols = 0;
+        struct stat sb;
+        if (fread(hdr, sizeof(uint64_t), 2, file) != 2 || fstat(fileno(file), &sb) != 0) { fclose(file); return false; }
+        if (!parse_bin_header(hdr, (uint64_t)sb.st_size, sizeof(FloatingType), &rows, &cols)) {
+            if (is_root()) fprintf(stderr, "Right hand side file is shorter than its header says\n");
+            fclose(file);
+            return false;
+        }
+        if (cols != 1) {
             if (is_root()) fprintf(stderr, "Right hand side has to have just a single column\n");
             fclose(file);
             return false;
         }
-        if (hdr[0] != _num_cols) {
+        if (rows != _num_cols) {
             if (is_root()) fprintf(stderr, "Size of right hand side does not match the matrix\n");
             fclose(file);
             return false;
         }
-        std::vector<FloatingType> b(hdr[0]);
-        const bool ok = fread(b.data(), sizeof(FloatingType), hdr[0], file) == hdr[0];
+        std::vector<FloatingType> b(rows);
+        bool ok = fread(b.data(), sizeof(FloatingType), rows, file) == rows;
         fclose(file);
-        if (!ok) return false;
-        if (lam_hip_set_rhs(_ctx, b.data()) != 0) return report("set_rhs");
-        return true;
+        if (ok && lam_hip_set_rhs(_ctx, b.data()) != 0) { report("set_rhs"); ok = false; }
+        return agree(ok);
     }
 
     bool save_result_to_file(const char *filename) const override
@@ -244,6 +268,13 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         return true;
     }
     bool is_root() const { return _rank == 0; }
+    // true iff the step succeeded on EVERY rank (collective in the one-process-per-GPU class)
+    bool agree(bool ok) const
+    {
+        int all = ok ? 1 : 0;
+        if (_ctx && lam_hip_all_ok(_ctx, ok ? 1 : 0, &all) != 0) return false;
+        return all != 0;
+    }
     bool report(const char *what) const
     {
         fprintf(stderr, "LAM HIP: %s failed: %s\n", what, lam_hip_last_error(_ctx));

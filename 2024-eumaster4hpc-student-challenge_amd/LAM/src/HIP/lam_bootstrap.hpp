@@ -6,7 +6,7 @@
 // (torchrun: RANK/WORLD_SIZE/LOCAL_RANK; MPICH/hydra: PMI_RANK/PMI_SIZE/MPI_LOCALRANKID; Open MPI:
 // OMPI_COMM_WORLD_*; Slurm: SLURM_PROCID/SLURM_NTASKS/SLURM_LOCALID) and the id through a file that
 // rank 0 publishes atomically (single node; the path can be put on a shared filesystem).  Compile
-// with -DLAM_USE_MPI to use MPI_Bcast instead.
+// with -DLAM_USE_MPI to use MPI_Bcast instead (taken whenever MPI has been initialised).
 #ifndef LAM_BOOTSTRAP_HPP
 #define LAM_BOOTSTRAP_HPP
 
@@ -19,7 +19,7 @@
 
 #include <unistd.h>
 
-#include "../../include/lam_hip.h"
+#include "../../../../include/lam_hip.h"
 
 #ifdef LAM_USE_MPI
 #include <mpi.h>
@@ -43,10 +43,42 @@ inline int env_int(std::initializer_list<const char *> names, int dflt)
     return dflt;
 }
 
+// Rendezvous file of this launch.  The key must be the same on all ranks of ONE launch and differ
+// between launches: LAM_RCCL_ID_FILE / LAM_JOB_ID if the caller sets them, else the launcher's
+// job id or port plus the pid of the launcher process, which all local ranks share as their parent.
+inline std::string id_file_path()
+{
+    if (const char *p = getenv("LAM_RCCL_ID_FILE")) return p;
+    const char *job = getenv("LAM_JOB_ID");
+    if (!job) job = getenv("MASTER_PORT");
+    if (!job) job = getenv("SLURM_JOB_ID");
+    if (!job) job = getenv("PMI_ID");
+    return std::string("/tmp/lam_rccl_id.") + (job ? job : "default") + "." + std::to_string((long)getppid());
+}
+
+// rank / size / local rank and the unique id, WITHOUT initialising MPI: for a class that is
+// default-constructed inside somebody else's driver (the reference's drivers call MPI_Init themselves,
+// test_CG_MultiGPUS_CUDA_NCCL.cpp:207-209).  With -DLAM_USE_MPI and MPI already initialised the id
+// travels by MPI_Bcast (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:320-327); otherwise through the
+// environment + the rendezvous file.
+inline bool attach(Launch &L);
+
 inline bool init(int *argc, char ***argv, Launch &L)
 {
 #ifdef LAM_USE_MPI
     MPI_Init(argc, argv);
+#else
+    (void)argc; (void)argv;
+#endif
+    return attach(L);
+}
+
+inline bool attach(Launch &L)
+{
+#ifdef LAM_USE_MPI
+    int mpi_up = 0;
+    MPI_Initialized(&mpi_up);
+    if (mpi_up) {
     MPI_Comm_rank(MPI_COMM_WORLD, &L.rank);
     MPI_Comm_size(MPI_COMM_WORLD, &L.size);
     MPI_Comm local;
@@ -58,24 +90,17 @@ inline bool init(int *argc, char ***argv, Launch &L)
         MPI_Bcast(L.unique_id, LAM_HIP_UNIQUE_ID_BYTES, MPI_BYTE, 0, MPI_COMM_WORLD);
     }
     return true;
-#else
-    (void)argc; (void)argv;
+    }
+#endif
     L.rank = env_int({"RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID"}, 0);
     L.size = env_int({"WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", "SLURM_NTASKS"}, 1);
     L.local_rank = env_int({"LOCAL_RANK", "MPI_LOCALRANKID", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}, L.rank);
     if (L.size <= 1) return true;
-    std::string path;
-    if (const char *p = getenv("LAM_RCCL_ID_FILE")) path = p;
-    else {
-        const char *job = getenv("LAM_JOB_ID");
-        if (!job) job = getenv("MASTER_PORT");
-        if (!job) job = getenv("SLURM_JOB_ID");
-        if (!job) job = getenv("PMI_ID");   // best effort; set LAM_JOB_ID for concurrent jobs
-        path = std::string("/tmp/lam_rccl_id.") + (job ? job : "default");
-    }
+    const std::string path = id_file_path();
     L.id_file = path;
     if (L.rank == 0) {
         if (lam_hip_get_unique_id(L.unique_id) != 0) return false;
+        unlink(path.c_str());              // whatever an earlier launch left under this name is not ours
         const std::string tmp = path + ".tmp";
         FILE *f = fopen(tmp.c_str(), "wb");
         if (!f || fwrite(L.unique_id, 1, LAM_HIP_UNIQUE_ID_BYTES, f) != LAM_HIP_UNIQUE_ID_BYTES) return false;
@@ -93,7 +118,6 @@ inline bool init(int *argc, char ***argv, Launch &L)
     }
     fprintf(stderr, "rank %d: timed out waiting for %s\n", L.rank, path.c_str());
     return false;
-#endif
 }
 
 // Call after the communicator has been created on this rank (ncclCommInitRank is collective, so by
@@ -106,11 +130,12 @@ inline void communicator_ready(const Launch &L)
 
 inline void finalize(const Launch &L)
 {
+    (void)L;
 #ifdef LAM_USE_MPI
-    (void)L;
-    MPI_Finalize();
-#else
-    (void)L;
+    int up = 0, down = 0;
+    MPI_Initialized(&up);
+    MPI_Finalized(&down);
+    if (up && !down) MPI_Finalize();
 #endif
 }
 

@@ -90,6 +90,9 @@ def lib():
             "lam_hip_check_symmetry": ([vp, C.POINTER(C.c_double)], i32),
             "lam_hip_dot": ([vp, vp, vp, u64, C.POINTER(C.c_double)], i32),
             "lam_hip_axpby": ([vp, C.c_double, vp, C.c_double, vp, u64], i32),
+            "lam_hip_all_ok": ([vp, i32, C.POINTER(i32)], i32),
+            "lam_hip_rccl_version": ([C.POINTER(i32)], i32),
+            "lam_hip_gemv_kernel_name": ([vp, C.c_char_p, C.c_size_t], i32),
             "lam_hip_set_option": ([vp, C.c_char_p, C.c_int64], i32),
             "lam_hip_get_option": ([vp, C.c_char_p, C.POINTER(C.c_int64)], i32),
         }
@@ -115,6 +118,14 @@ def get_unique_id():
     if rc != 0:
         raise LamHipError(rc, (lib().lam_hip_last_error(None) or b"").decode())
     return buf.raw
+
+
+def rccl_version():
+    v = C.c_int(0)
+    rc = lib().lam_hip_rccl_version(C.byref(v))
+    if rc != 0:
+        raise LamHipError(rc, (lib().lam_hip_last_error(None) or b"").decode())
+    return v.value
 
 
 def partition(n, num_shards, shard):
@@ -339,6 +350,16 @@ class Solver:
         v = C.c_double()
         self._chk(self._L.lam_hip_check_symmetry(self._h, C.byref(v)))
         return v.value
+
+    def all_ok(self, ok):
+        g = C.c_int(0)
+        self._chk(self._L.lam_hip_all_ok(self._h, 1 if ok else 0, C.byref(g)))
+        return bool(g.value)
+
+    def gemv_kernel_name(self):
+        buf = C.create_string_buffer(256)
+        self._chk(self._L.lam_hip_gemv_kernel_name(self._h, buf, 256))
+        return buf.value.decode()
 
     def get_option(self, name):
         v = C.c_int64()

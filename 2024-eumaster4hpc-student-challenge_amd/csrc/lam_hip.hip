@@ -4,15 +4,19 @@
 // Orchestration of the loop body of
 //   /root/reference/challenge/main/LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:98-116
 // per shard and iteration k:
-//   gemv_tile_kernel -> [reduce p.Ap across shards] -> update_xr_kernel -> [reduce r.r across
-//   shards] -> update_p_kernel (stores the new p slice into every replica of p) -> [all-gather p]
-// "Across shards" is (a) nothing for one shard, (b) direct peer stores + cross-stream events when
-// one process drives several shards (xGMI point-to-point), (c) RCCL when there is one process per
-// GPU: ncclAllReduce x2 + ncclAllGather(p) on a second stream under the own-slice GEMV panel
+//   gemv_coop_kernel -> [exchange p.Ap partials] -> update_xr_kernel -> [exchange r.r partials]
+//   -> update_p_kernel (stores the new p slice into every replica of p) -> [all-gather p]
+// With several shards the last workgroup of the producer kernel leaves the shard's partial as one
+// double (lam_kernels.h, Finalize), so an iteration is 3 launches for every shard count.  "Exchange"
+// is (a) nothing for one shard, (b) direct peer stores + cross-stream events when one process drives
+// several shards (xGMI point-to-point), (c) RCCL when there is one process per GPU: an 8-byte-per-
+// rank ncclAllGather for each dot product (summed in rank order by the consumer: deterministic and
+// bit-identical to (b)) + ncclAllGather(p) on a second stream under the own-slice GEMV panel
 // (exchange 0), or one ncclAllGather of [Ap slice | p.Ap partial] with full-length r/p per rank
-// (exchange 1).  Scalars stay on the device; the host only polls a stop flag with a lag of kLag
-// iterations, so the queue never drains.  Option "symmetric" (one shard) replaces the GEMV by the
-// two-pass upper-triangle product.
+// (exchange 1).  Scalars stay on the device; the host only reads the stopping iteration from pinned
+// memory with a lag of kLag iterations, so the queue never drains and every rank enqueues the same
+// number of collectives.  Option "symmetric" (one shard) replaces the GEMV by the two-pass
+// upper-triangle product.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -51,6 +55,7 @@ struct ShardBase {
     uint64_t row0 = 0, nrows = 0;
     hipStream_t stream = nullptr;
     void *A = nullptr;           // nrows x n
+    size_t A_capacity = 0;       // bytes behind A: the allocation is kept across lam_hip_set_problem calls (grow-only)
     void *p = nullptr;           // n (replica)
     void *Ap = nullptr, *x = nullptr, *r = nullptr, *b = nullptr;  // nrows each
     void *tmp = nullptr;         // n: scratch vector (gemv op input / residual)
@@ -63,6 +68,7 @@ struct ShardBase {
     double *part_vec = nullptr;  // [vec_blocks]
     double *gather_a = nullptr;  // [kMaxShards] p.Ap partials of all shards (or the reduced scalar at [0])
     double *gather_b = nullptr;  // [kMaxShards] r.r partials
+    unsigned *tickets = nullptr; // [2] arrival counters of the in-kernel reductions (GEMV, update_xr)
     CgScalars *sc = nullptr;     // device scalars
     CgScalars *sc_host = nullptr;// pinned mirror (filled by an async copy at the end of a call)
     int *host_flags = nullptr;   // pinned, device-visible: [0] last finished iteration, [1] stop
@@ -99,7 +105,12 @@ struct lam_hip_ctx {
     int64_t opt_panel_lo = 0, opt_panel_hi = 0;  // testing: split the CG GEMV into [lo,hi) + the rest
     bool gather_pending = false;   // an all-gather of p is in flight on comm_stream
     int64_t opt_symmetric = 0;     // single shard: read only the upper triangle (caller asserts A == A^T)
-    int64_t opt_exchange = 0;      // rank mode: 0 = all-reduce x2 + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
+    int64_t opt_exchange = 0;      // rank mode: 0 = all-gather x2 (8 B/rank) + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
+    int64_t opt_reuse_matrix = 1;  // lam_hip_set_problem keeps (and re-uses) the matrix allocation when it is large enough
+    int64_t opt_upload_staging = 0; // lam_hip_upload_rows: 1 = pipeline through two pinned staging buffers
+    int64_t opt_finalize = 1;      // several shards: 1 = producer kernels reduce their partials themselves (Finalize);
+                                   // 0 = separate 1-block finalize_sum_kernel launches (A/B measurements)
+    uint64_t n_collectives = 0;    // RCCL calls enqueued by this context (diagnostics: must match across ranks)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
     // the symmetric product exists for one shard, fp64/fp32 storage, n a multiple of its column tile
@@ -164,6 +175,17 @@ void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
     *nrows = base + ((q == P - 1) ? n % (uint64_t)P : 0);
 }
 
+// temporaries of one call: released on every exit path (HIPCHK returns from the middle of a function)
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+struct PinnedBuf {
+    void *p = nullptr;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
 int vec_grid(uint64_t n_loc)
 {
     uint64_t b = (n_loc + kBlock - 1) / kBlock;
@@ -196,6 +218,34 @@ struct Impl {
         // production shapes: fp64/fp32 -> cooperative rows (variant 10); bf16 storage spends more VALU
         // per byte (widening) and measures best with 4 rows per wave (variant 0, 6.77 vs 6.40 TB/s)
         return sizeof(TA) == 2 ? 0 : 10;
+    }
+
+    // name of the kernel instantiation launch_gemv() picks for this context (roofline records)
+    static std::string kernel_name(const lam_hip_ctx *c)
+    {
+        const char *ta = sizeof(TA) == 8 ? "double" : (sizeof(TA) == 4 ? "float" : "__hip_bfloat16");
+        const char *tv = sizeof(TV) == 8 ? "double" : "float";
+        char buf[192];
+        if (c->symv_active()) { snprintf(buf, sizeof buf, "symv_task_kernel<%s> + symv_reduce_kernel<%s>", ta, ta); return buf; }
+        if (!fast_ok(c)) { snprintf(buf, sizeof buf, "gemv_generic_kernel<%s,%s>", ta, tv); return buf; }
+        const int v = variant(c);
+        const char *nt = c->opt_nt ? "true" : "false";
+        struct Tile { int r, tile; bool lds, rot; };
+        static const Tile tiles[9] = {{4, 4096, true, true}, {2, 4096, true, true}, {8, 4096, true, true}, {4, 2048, true, true},
+                                      {4, 8192, true, true}, {2, 8192, true, true}, {4, 4096, false, true}, {4, 4096, true, false},
+                                      {1, 4096, true, true}};
+        struct Coop { int r, tile, waves, unroll; };
+        static const Coop coops[10] = {{1, 4096, 4, 4}, {2, 4096, 4, 4}, {4, 4096, 4, 4}, {8, 4096, 4, 4}, {2, 4096, 8, 4},
+                                       {2, 2048, 4, 4}, {2, 8192, 8, 8}, {2, 8192, 4, 8}, {4, 4096, 8, 4}, {3, 4096, 4, 4}};
+        if (v <= 8)
+            snprintf(buf, sizeof buf, "gemv_tile_kernel<%s,%s,R=%d,TILE=%d,NT=%s,UNROLL=4,LDS=%s,ROT=%s>", ta, tv, tiles[v].r,
+                     tiles[v].tile, nt, tiles[v].lds ? "true" : "false", tiles[v].rot ? "true" : "false");
+        else if (v <= 18)
+            snprintf(buf, sizeof buf, "gemv_coop_kernel<%s,%s,R=%d,TILE=%d,NT=%s,UNROLL=%d,WAVES=%d>", ta, tv, coops[v - 9].r,
+                     coops[v - 9].tile, nt, coops[v - 9].unroll, coops[v - 9].waves);
+        else
+            snprintf(buf, sizeof buf, "gemv_mfma_bf16_kernel<variant %d>", v);
+        return buf;
     }
 
     // number of p.Ap partials the product step of a CG iteration leaves in part_gemv
@@ -233,11 +283,15 @@ struct Impl {
                 std::vector<SymvTask> tasks;
                 for (uint32_t I = 0; I < nblk; I++)
                     for (uint32_t j = (uint32_t)(((uint64_t)I * kSymvRows) / SymvShape<TA>::TILE); j < ntiles; j++) tasks.push_back({I, j});
-                HIPCHK(c, hipMalloc((void **)&s.symv_tasks, tasks.size() * sizeof(SymvTask)));
-                HIPCHK(c, hipMalloc(&s.symv_rowpart, (size_t)nblk * ntiles * kSymvRows * sizeof(TA)));
-                HIPCHK(c, hipMalloc(&s.symv_colpart, (size_t)nblk * n * sizeof(TA)));
-                HIPCHK(c, hipMemcpy(s.symv_tasks, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
-                HIPCHK(c, hipMemsetAsync(s.symv_colpart, 0, (size_t)nblk * n * sizeof(TA), s.stream));
+                // all three or none: a later failure must not leave the earlier buffers behind
+                DevBuf t, rp, cp;
+                HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
+                HIPCHK(c, hipMalloc(&rp.p, (size_t)nblk * ntiles * kSymvRows * sizeof(TA)));
+                HIPCHK(c, hipMalloc(&cp.p, (size_t)nblk * n * sizeof(TA)));
+                HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMemsetAsync(cp.p, 0, (size_t)nblk * n * sizeof(TA), s.stream));
+                s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p;
+                t.p = rp.p = cp.p = nullptr;
                 s.symv_ntasks = (int)tasks.size();
             }
             hipLaunchKernelGGL((symv_task_kernel<TA>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
@@ -263,11 +317,13 @@ struct Impl {
     }
 
     static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc,
-                           int panel = 0, uint64_t lo = 0, uint64_t hi = 0)
+                           int panel = 0, uint64_t lo = 0, uint64_t hi = 0, const Finalize *fin = nullptr)
     {
         if (s.nrows == 0) return 0;
         GemvArgs<TA, TV> a;
         a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
+        if (fin != nullptr && partial != nullptr) a.fin = *fin;
+        else { a.fin.ticket = nullptr; a.fin.dst.n = 0; a.fin.slot = 0; }
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
         a.seg_begin[0] = 0; a.seg_end[0] = c->n; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
         if (panel == 1) { a.seg_begin[0] = lo; a.seg_end[0] = hi; }
@@ -371,11 +427,15 @@ PtrList plist_gather(lam_hip_ctx *c, bool second)
     return l;
 }
 
-void free_shard(ShardBase &s)
+// keep_matrix: leave the matrix allocation alone (lam_hip_set_problem re-uses it when it is large enough)
+void free_shard(ShardBase &s, bool keep_matrix = false)
 {
     if (hipSetDevice(s.dev) != hipSuccess) { (void)hipGetLastError(); return; }   // never created on a real device
+    void *const keepA = keep_matrix ? s.A : nullptr;
+    const size_t keepCap = keep_matrix ? s.A_capacity : 0;
+    if (keep_matrix) s.A = nullptr;
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
-                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks};
+                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.tickets};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = nullptr;
     s.symv_tasks = nullptr;
@@ -384,7 +444,10 @@ void free_shard(ShardBase &s)
     if (s.host_flags) (void)hipHostFree(s.host_flags);
     s.host_flags = nullptr;
     s.A = s.p = s.Ap = s.x = s.r = s.b = s.tmp = nullptr;
+    s.A = keepA;
+    s.A_capacity = keepCap;
     s.part_gemv = s.part_vec = s.gather_a = s.gather_b = nullptr;
+    s.tickets = nullptr;
     s.sc = nullptr; s.sc_host = nullptr;
 }
 
@@ -468,38 +531,55 @@ int sync_all(lam_hip_ctx *c)
     return 0;
 }
 
-// Reduce the per-workgroup partials in `part` (n_part values) of every local shard into the
-// array the next kernel sums.  Returns through (*red, *nred) what that kernel must read.
-//   1 shard            : the partials themselves
-//   several, 1 process : finalize -> slot q of every shard's gather array (peer stores) + events
-//   rank mode          : finalize -> gather[0], ncclAllReduce in place
-int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop)
+// Where the reduced partial of shard `s` goes (see lam_kernels.h, Finalize): slot `index` of the
+// gather array of every local shard (one process: peer stores) or of this rank (rank mode).
+Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
+{
+    Finalize f;
+    f.ticket = nullptr;
+    f.dst.n = 0;
+    f.slot = s.index;
+    if (!c->rank_mode && c->total_shards == 1) return f;
+    if (c->rank_mode) { f.dst.n = 1; f.dst.p[0] = second ? s.gather_b : s.gather_a; }
+    else {
+        f.dst.n = (int)c->sh.size();
+        for (int j = 0; j < f.dst.n; j++) f.dst.p[j] = second ? (void *)c->sh[j].gather_b : (void *)c->sh[j].gather_a;
+    }
+    if (c->opt_finalize) f.ticket = s.tickets + (second ? 1 : 0);
+    return f;
+}
+
+// Exchange the shards' partials of a dot product so that the next kernel can sum them in shard order.
+//   1 shard            : nothing (the consumer sums the workgroup partials)
+//   several, 1 process : the producer's last workgroup stored the shard's partial into slot q of every
+//                        shard's gather array (peer stores); events order the consumers behind them
+//   rank mode          : in-place ncclAllGather of the 8-byte partials (slot = rank)
+// `finalized` = the producer kernel already reduced its partials (Finalize); otherwise a 1-block
+// finalize_sum_kernel does it here (cg_init, and option "finalize" = 0).
+int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop, bool finalized)
 {
     const int L = (int)c->sh.size();
     if (!c->rank_mode && c->total_shards == 1) return 0;
-    if (c->rank_mode) {
-        ShardBase &s = c->sh[0];
-        PtrList dst; dst.n = 1; dst.p[0] = second ? s.gather_b : s.gather_a;
-        const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
-        const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
-        hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, dst, 0,
-                           check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
-        HIPCHK(c, hipGetLastError());
-        double *buf = second ? s.gather_b : s.gather_a;
-        NCCLCHK(c, ncclAllReduce(buf, buf, 1, ncclDouble, ncclSum, c->comm, s.stream));
-        return 0;
-    }
-    PtrList dst = plist_gather(c, second);
     for (int q = 0; q < L; q++) {
         ShardBase &s = c->sh[q];
         LAMCHK(set_dev(c, s));
-        const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
-        const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
-        hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, dst, s.index,
-                           check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(second ? s.ev_b : s.ev_a, s.stream));
+        if (!finalized) {
+            Finalize f = make_finalize(c, s, second);
+            const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
+            const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
+            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, f.dst, f.slot,
+                               check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (c->rank_mode) {
+            double *buf = second ? s.gather_b : s.gather_a;
+            NCCLCHK(c, ncclAllGather(buf + c->rank, buf, 1, ncclDouble, c->comm, s.stream));
+            c->n_collectives++;
+        } else {
+            HIPCHK(c, hipEventRecord(second ? s.ev_b : s.ev_a, s.stream));
+        }
     }
+    if (c->rank_mode) return 0;
     for (int q = 0; q < L; q++) {
         ShardBase &s = c->sh[q];
         LAMCHK(set_dev(c, s));
@@ -514,12 +594,9 @@ void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, c
     if (!c->rank_mode && c->total_shards == 1) {
         *red = use_gemv_part ? s.part_gemv : s.part_vec;
         *nred = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
-    } else if (c->rank_mode) {
-        *red = second ? s.gather_b : s.gather_a;
-        *nred = 1;
     } else {
         *red = second ? s.gather_b : s.gather_a;
-        *nred = c->total_shards;
+        *nred = c->total_shards;       // == nranks in rank mode
     }
 }
 
@@ -552,6 +629,7 @@ int gather_p_step(lam_hip_ctx *c)
         } done{c, s, cs};
         if (c->n % (uint64_t)c->nranks == 0) {
             NCCLCHK(c, ncclAllGather((const char *)s.p + s.row0 * ev, s.p, base, dt, c->comm, cs));
+            c->n_collectives++;
             return done.finish();
         } else {
             // uneven last block (reference: MPI_Allgatherv): one broadcast per owner
@@ -561,6 +639,7 @@ int gather_p_step(lam_hip_ctx *c)
                 partition(c->n, c->nranks, q, &r0, &nr);
                 char *ptr = (char *)s.p + r0 * ev;
                 NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, cs));
+                c->n_collectives++;
             }
             NCCLCHK(c, ncclGroupEnd());
         }
@@ -597,6 +676,7 @@ int do_cg_init_exchange1(lam_hip_ctx *c)
         LAMCHK(set_dev(c, s));
         const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
         NCCLCHK(c, ncclAllGather(s.b, s.r_full, c->ex1_base(), dt, c->comm, s.stream));   // r_full = b
+        c->n_collectives++;
         const int grid = vec_grid(c->n);
         hipLaunchKernelGGL((cg_init_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (TV *)s.r_full, (TV *)s.p,
                            (TV *)s.x, c->n, s.nrows, s.part_vec);
@@ -619,15 +699,22 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         LAMCHK(set_dev(c, s));
         const uint64_t stride = c->ex1_stride_bytes(), base = c->ex1_base();
         char *rec = (char *)s.ap_gather + (uint64_t)c->rank * stride;
-        // 1. GEMV straight into this rank's record, then its p.Ap partial behind the slice
+        // 1. GEMV straight into this rank's record; its last workgroup leaves the rank's p.Ap partial
+        //    behind the slice (with option "finalize" = 0: a 1-block launch does)
+        Finalize f;
+        f.ticket = c->opt_finalize ? s.tickets : nullptr;
+        f.dst.n = 1; f.dst.p[0] = rec + base * sizeof(TV); f.slot = 0;
         HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
-        LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc));
+        LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc, 0, 0, 0, &f));
         HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
-        hipLaunchKernelGGL(finalize_tail_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, s.gemv_blocks,
-                           rec, base * sizeof(TV), (const CgScalars *)s.sc);
-        HIPCHK(c, hipGetLastError());
+        if (!c->opt_finalize) {
+            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, s.gemv_blocks,
+                               f.dst, 0, (const CgScalars *)s.sc);
+            HIPCHK(c, hipGetLastError());
+        }
         // 2. the iteration's only collective
         NCCLCHK(c, ncclAllGather(rec, s.ap_gather, stride, ncclChar, c->comm, s.stream));
+        c->n_collectives++;
         // 3. alpha, x slice, FULL r (+ partials of r.r over the full vector: no collective needed)
         const int grid = vec_grid(c->n);
         hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
@@ -654,7 +741,7 @@ int do_cg_init(lam_hip_ctx *c)
                                (TV *)s.x, (TV *)s.r, pl, s.row0, s.nrows, s.part_vec);
             HIPCHK(c, hipGetLastError());
         }
-        LAMCHK(reduce_step(c, /*second=*/true, /*gemv_part=*/false, /*check_stop=*/false));
+        LAMCHK(reduce_step(c, /*second=*/true, /*gemv_part=*/false, /*check_stop=*/false, /*finalized=*/false));
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             const double *red; int nred;
@@ -689,6 +776,7 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
                 continue;
             }
             s.split_slot[slot] = hi > lo;
+            const Finalize fa = make_finalize(c, s, false);
             if (hi > lo) {
                 // the two panels are timed separately so that t_gemv is kernel time, not the wait in between
                 HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
@@ -696,27 +784,29 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
                 HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
                 if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
                 HIPCHK(c, hipEventRecord(s.ev_g2[slot], s.stream));
-                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi));
+                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi, &fa));
                 HIPCHK(c, hipEventRecord(s.ev_g3[slot], s.stream));
             } else {
                 if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
                 HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
-                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 0, 0, 0, &fa));
                 HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
             }
         }
         c->gather_pending = false;
-        LAMCHK(reduce_step(c, false, true, true));
+        const bool fin = c->opt_finalize != 0;
+        LAMCHK(reduce_step(c, false, true, true, fin));
         // 2. x, r update + partial r.r
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             const double *red; int nred;
             red_source(c, s, false, true, &red, &nred);
             hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
-                               (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec);
+                               (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec,
+                               make_finalize(c, s, true));
             HIPCHK(c, hipGetLastError());
         }
-        LAMCHK(reduce_step(c, true, false, true));
+        LAMCHK(reduce_step(c, true, false, true, fin));
         // 3. stop test + p update (into every replica)
         PtrList pl = plist_p(c);
         for (auto &s : c->sh) {
@@ -856,10 +946,19 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
     c->have_problem = c->have_matrix = c->have_rhs = c->cg_ready = false;
     const size_t ea = c->esz_a(), ev = c->esz_v();
     for (auto &s : c->sh) {
-        free_shard(s);
+        // The matrix allocation is grow-only: a context that loads a smaller system after a large one keeps
+        // streaming from the pages it already owns instead of handing 34 GB back to the runtime and carving
+        // a new block out of whatever that leaves behind ("allocation history").
+        // Option "reuse_matrix" = 0 restores free + hipMalloc.
+        free_shard(s, c->opt_reuse_matrix != 0);
         partition(n, c->total_shards, s.index, &s.row0, &s.nrows);
         LAMCHK(set_dev(c, s));
-        HIPCHK(c, hipMalloc(&s.A, std::max<size_t>(16, s.nrows * n * ea)));
+        const size_t needA = std::max<size_t>(16, s.nrows * n * ea);
+        if (s.A != nullptr && s.A_capacity < needA) { (void)hipFree(s.A); s.A = nullptr; s.A_capacity = 0; }
+        if (s.A == nullptr) {
+            HIPCHK(c, hipMalloc(&s.A, needA));
+            s.A_capacity = needA;
+        }
         HIPCHK(c, hipMalloc(&s.p, n * ev + 16));
         HIPCHK(c, hipMalloc(&s.tmp, n * ev + 16));
         void **vecs[] = {&s.Ap, &s.x, &s.r, &s.b};
@@ -872,6 +971,8 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         HIPCHK(c, hipMalloc((void **)&s.part_vec, sizeof(double) * kVecBlocksMax));
         HIPCHK(c, hipMalloc((void **)&s.gather_a, sizeof(double) * kMaxShards));
         HIPCHK(c, hipMalloc((void **)&s.gather_b, sizeof(double) * kMaxShards));
+        HIPCHK(c, hipMalloc((void **)&s.tickets, 64));
+        HIPCHK(c, hipMemsetAsync(s.tickets, 0, 64, s.stream));
         if (c->rank_mode) {
             HIPCHK(c, hipMalloc(&s.r_full, n * ev + 16));
             HIPCHK(c, hipMalloc(&s.ap_gather, (size_t)c->nranks * ((n / (uint64_t)c->nranks + 1) * ev + 8) + 16));
@@ -938,8 +1039,9 @@ static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, 
         if (c->dtype == LAM_HIP_BF16) {
             // stage through a device float buffer in chunks of rows
             const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / (c->n * 4));
-            float *stage = nullptr;
-            HIPCHK(c, hipMalloc((void **)&stage, chunk_rows * c->n * 4));
+            DevBuf stage_buf;
+            HIPCHK(c, hipMalloc(&stage_buf.p, chunk_rows * c->n * 4));
+            float *stage = stage_buf.as<float>();
             for (uint64_t r = lo; r < hi; r += chunk_rows) {
                 const uint64_t nr = std::min(chunk_rows, hi - r), ne = nr * c->n;
                 char *hp = (char *)host + (r - row0) * c->n * 4;
@@ -957,7 +1059,27 @@ static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, 
                     for (uint64_t i = 0; i < ne; i++) { unsigned u = ((unsigned)tmp[i]) << 16; memcpy(&fp[i], &u, 4); }
                 }
             }
-            HIPCHK(c, hipFree(stage));
+        } else if (upload && c->opt_upload_staging) {
+            // Option "upload_staging": pipeline through two pinned buffers -- a host memcpy into one
+            // while the DMA engine drains the other.  Measured against the default (the runtime pins the
+            // caller's pages and DMAs from them directly): see DESIGN.md section 6, f1.
+            const uint64_t stage_elems = (64ull << 20) / ea;
+            PinnedBuf pin[2];
+            hipEvent_t evs[2] = {nullptr, nullptr};
+            struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } evg{evs};
+            for (int i = 0; i < 2; i++) {
+                HIPCHK(c, hipHostMalloc(&pin[i].p, stage_elems * ea, hipHostMallocDefault));
+                HIPCHK(c, hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
+            }
+            int b = 0;
+            for (uint64_t off = 0; off < cnt; off += stage_elems, b ^= 1) {
+                const uint64_t ne = std::min(stage_elems, cnt - off);
+                HIPCHK(c, hipEventSynchronize(evs[b]));                    // the DMA that last used this buffer is done
+                memcpy(pin[b].p, hptr + off * ea, ne * ea);
+                HIPCHK(c, hipMemcpyAsync(dptr + off * ea, pin[b].p, ne * ea, hipMemcpyHostToDevice, s.stream));
+                HIPCHK(c, hipEventRecord(evs[b], s.stream));
+            }
+            HIPCHK(c, hipStreamSynchronize(s.stream));
         } else {
             // chunked so that a single call never exceeds 2^31 elements (the reference's int-count trap)
             const uint64_t chunk = 1ull << 28;
@@ -1097,14 +1219,23 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         const int k = k_first + i;
         const int slot = i % kLag;
         if (i >= kLag) {
-            // The iteration enqueued kLag steps ago is done: harvest its GEMV time and stop flag.
-            // The flag is stored by update_p_kernel before that iteration's event, so a stop at loop
-            // index j is seen exactly at i = j + kLag on every rank: all ranks enqueue the same
-            // number of (no-op) iterations and their collectives stay matched.
+            // Iteration k - kLag (enqueued kLag steps ago) is done: harvest its GEMV time, then look at
+            // the stopping iteration update_p_kernel stores into pinned memory.  Later iterations may
+            // or may not have finished by now -- that depends on how far this rank's GPU is ahead of
+            // its host -- so the value only counts if it names an iteration whose completion has been
+            // AWAITED: flag <= k - kLag.  A stop at iteration j is therefore acted on at k = j + kLag
+            // on every rank, whatever the timing: all ranks enqueue the same number of (no-op)
+            // iterations and their collectives stay matched.  (The reference broadcasts the decision
+            // instead: MPI_Bcast(&stop), ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:404-407.)
             LAMCHK(set_dev(c, s0));
             HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
             harvest(slot);
-            if (((volatile int *)s0.host_flags)[1]) { stopped = true; break; }
+            const int stop_at = ((volatile int *)s0.host_flags)[1];
+            // LAM_HIP_DEBUG_LEVEL_STOP: test hook that restores the timing-dependent decision ("any stop
+            // seen so far") so that the stream-ordered RCCL test double can be shown to catch the rank
+            // desynchronisation it causes (tests/test_gpu_rank_mock.py).  Never set it otherwise.
+            static const bool level_stop = getenv("LAM_HIP_DEBUG_LEVEL_STOP") != nullptr;
+            if (stop_at != 0 && (stop_at <= k - kLag || level_stop)) { stopped = true; break; }
         }
         LAMCHK(enqueue_iteration(c, k, rel_error, slot));
         LAMCHK(set_dev(c, s0));
@@ -1166,6 +1297,7 @@ int lam_hip_get_solution(lam_hip_ctx *c, void *x_host)
             partition(c->n, c->nranks, q, &r0, &nr);
             char *ptr = (char *)s.tmp + r0 * ev;
             NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+            c->n_collectives++;
         }
         NCCLCHK(c, ncclGroupEnd());
         HIPCHK(c, hipMemcpyAsync(x_host, s.tmp, c->n * ev, hipMemcpyDeviceToHost, s.stream));
@@ -1225,6 +1357,7 @@ int lam_hip_gemv(lam_hip_ctx *c, const void *x_host, void *y_host)
             partition(c->n, c->nranks, q, &r0, &nr);
             char *ptr = (char *)s.tmp + r0 * ev;
             NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+            c->n_collectives++;
         }
         NCCLCHK(c, ncclGroupEnd());
         HIPCHK(c, hipMemcpyAsync(y_host, s.tmp, c->n * ev, hipMemcpyDeviceToHost, s.stream));
@@ -1299,6 +1432,7 @@ int lam_hip_true_residual(lam_hip_ctx *c, double *rel_res)
             partition(c->n, c->nranks, q, &r0, &nr);
             char *ptr = (char *)s.tmp + r0 * ev;
             NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+            c->n_collectives++;
         }
         NCCLCHK(c, ncclGroupEnd());
     } else {
@@ -1336,6 +1470,7 @@ int lam_hip_true_residual(lam_hip_ctx *c, double *rel_res)
         double hv[2] = {num, den};
         HIPCHK(c, hipMemcpyAsync(s.gather_a, hv, sizeof hv, hipMemcpyHostToDevice, s.stream));
         NCCLCHK(c, ncclAllReduce(s.gather_a, s.gather_a, 2, ncclDouble, ncclSum, c->comm, s.stream));
+        c->n_collectives++;
         HIPCHK(c, hipMemcpyAsync(hv, s.gather_a, sizeof hv, hipMemcpyDeviceToHost, s.stream));
         HIPCHK(c, hipStreamSynchronize(s.stream));
         num = hv[0]; den = hv[1];
@@ -1354,18 +1489,17 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
         ShardBase &s = c->sh[0];
         LAMCHK(set_dev(c, s));
         const int grid = 2048;
-        double *out = nullptr;
-        HIPCHK(c, hipMalloc((void **)&out, sizeof(double) * grid));
+        DevBuf outb;
+        HIPCHK(c, hipMalloc(&outb.p, sizeof(double) * grid));
+        double *out = outb.as<double>();
         std::vector<double> h(grid);
         if constexpr (sizeof(TA) == 2) {
-            (void)hipFree(out);
             return fail(c, LAM_HIP_EINVAL, "symmetry check is implemented for fp64/fp32 storage");
         } else {
             hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->n, out);
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(h.data(), out, sizeof(double) * grid, hipMemcpyDeviceToHost, s.stream);
             if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-            (void)hipFree(out);
             if (e != hipSuccess) return fail(c, LAM_HIP_EHIP, "symmetry check: %s", hipGetErrorString(e));
             double m = 0.0;
             for (double v : h) m = std::max(m, v);
@@ -1381,11 +1515,12 @@ int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t
     ShardBase &s = c->sh[0];
     LAMCHK(set_dev(c, s));
     const size_t ev = c->esz_v();
-    void *dx = nullptr, *dy = nullptr;
-    double *part = nullptr;
-    HIPCHK(c, hipMalloc(&dx, n * ev + 16));
-    HIPCHK(c, hipMalloc(&dy, n * ev + 16));
-    HIPCHK(c, hipMalloc((void **)&part, sizeof(double) * kVecBlocksMax));
+    DevBuf bx, by, bpart;
+    HIPCHK(c, hipMalloc(&bx.p, n * ev + 16));
+    HIPCHK(c, hipMalloc(&by.p, n * ev + 16));
+    HIPCHK(c, hipMalloc(&bpart.p, sizeof(double) * kVecBlocksMax));
+    void *dx = bx.p, *dy = by.p;
+    double *part = bpart.as<double>();
     HIPCHK(c, hipMemcpyAsync(dx, x_host, n * ev, hipMemcpyHostToDevice, s.stream));
     HIPCHK(c, hipMemcpyAsync(dy, y_host, n * ev, hipMemcpyHostToDevice, s.stream));
     const int grid = vec_grid(n);
@@ -1404,7 +1539,6 @@ int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t
         for (int i = 0; i < grid; i++) t += h[i];   // fixed order: reproducible
         *result = t;
     }
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(part);
     return rc;
 }
 
@@ -1414,9 +1548,10 @@ int lam_hip_axpby(lam_hip_ctx *c, double alpha, const void *x_host, double beta,
     ShardBase &s = c->sh[0];
     LAMCHK(set_dev(c, s));
     const size_t ev = c->esz_v();
-    void *dx = nullptr, *dy = nullptr;
-    HIPCHK(c, hipMalloc(&dx, n * ev + 16));
-    HIPCHK(c, hipMalloc(&dy, n * ev + 16));
+    DevBuf bx, by;
+    HIPCHK(c, hipMalloc(&bx.p, n * ev + 16));
+    HIPCHK(c, hipMalloc(&by.p, n * ev + 16));
+    void *dx = bx.p, *dy = by.p;
     HIPCHK(c, hipMemcpyAsync(dx, x_host, n * ev, hipMemcpyHostToDevice, s.stream));
     HIPCHK(c, hipMemcpyAsync(dy, y_host, n * ev, hipMemcpyHostToDevice, s.stream));
     int rc = dispatch(c, [&](auto impl) -> int {
@@ -1430,8 +1565,47 @@ int lam_hip_axpby(lam_hip_ctx *c, double alpha, const void *x_host, double beta,
         if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
         if (e != hipSuccess) rc = fail(c, LAM_HIP_EHIP, "axpby readback: %s", hipGetErrorString(e));
     }
-    (void)hipFree(dx); (void)hipFree(dy);
     return rc;
+}
+
+int lam_hip_all_ok(lam_hip_ctx *c, int local_ok, int *global_ok)
+{
+    if (!c || !global_ok) return LAM_HIP_EINVAL;
+    *global_ok = local_ok ? 1 : 0;
+    if (!c->rank_mode) return 0;
+    ShardBase &s = c->sh[0];
+    LAMCHK(set_dev(c, s));
+    DevBuf buf;
+    HIPCHK(c, hipMalloc(&buf.p, sizeof(double)));
+    double v = local_ok ? 0.0 : 1.0;       // number of ranks that failed
+    HIPCHK(c, hipMemcpyAsync(buf.p, &v, sizeof v, hipMemcpyHostToDevice, s.stream));
+    NCCLCHK(c, ncclAllReduce(buf.p, buf.p, 1, ncclDouble, ncclSum, c->comm, s.stream));
+    c->n_collectives++;
+    HIPCHK(c, hipMemcpyAsync(&v, buf.p, sizeof v, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(c, hipStreamSynchronize(s.stream));
+    *global_ok = v == 0.0 ? 1 : 0;
+    return 0;
+}
+
+int lam_hip_rccl_version(int *version)
+{
+    if (!version) return LAM_HIP_EINVAL;
+    ncclResult_t r = ncclGetVersion(version);
+    if (r != ncclSuccess) return fail(nullptr, LAM_HIP_ERCCL, "ncclGetVersion: %s", ncclGetErrorString(r));
+    return 0;
+}
+
+int lam_hip_gemv_kernel_name(const lam_hip_ctx *c, char *buf, size_t len)
+{
+    if (!c || !buf || len == 0) return LAM_HIP_EINVAL;
+    std::string name;
+    switch (c->dtype) {
+    case LAM_HIP_F64: name = Impl<double, double>::kernel_name(c); break;
+    case LAM_HIP_F32: name = Impl<float, float>::kernel_name(c); break;
+    default: name = Impl<__hip_bfloat16, float>::kernel_name(c); break;
+    }
+    snprintf(buf, len, "%s", name.c_str());
+    return 0;
 }
 
 int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
@@ -1443,6 +1617,9 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
     else if (!strcmp(name, "overlap")) c->opt_overlap = value;
     else if (!strcmp(name, "exchange")) { c->opt_exchange = value; c->cg_ready = false; }
+    else if (!strcmp(name, "finalize")) c->opt_finalize = value;
+    else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
+    else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
     else if (!strcmp(name, "symmetric")) c->opt_symmetric = value;
     else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
     else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;
@@ -1462,6 +1639,10 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "probe_rows")) *value = c->opt_probe_rows;
     else if (!strcmp(name, "overlap")) *value = c->opt_overlap;
     else if (!strcmp(name, "exchange")) *value = c->opt_exchange;
+    else if (!strcmp(name, "finalize")) *value = c->opt_finalize;
+    else if (!strcmp(name, "upload_staging")) *value = c->opt_upload_staging;
+    else if (!strcmp(name, "reuse_matrix")) *value = c->opt_reuse_matrix;
+    else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
     else if (!strcmp(name, "symmetric")) *value = c->opt_symmetric;
     else if (!strcmp(name, "symmetric_effective")) *value = c->symv_active() ? 1 : 0;
     else if (!strcmp(name, "exchange_effective")) *value = c->exchange1_ok() ? 1 : 0;

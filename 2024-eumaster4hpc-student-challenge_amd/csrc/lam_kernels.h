@@ -63,7 +63,7 @@ __device__ __forceinline__ double block_sum(double v, double *s_red /*[kWaves]*/
 {
     v = wave_sum(v);
     __syncthreads();  // s_red may still be read from a previous call
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < kWaves) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = s_red[0];
 #pragma unroll
@@ -87,6 +87,68 @@ __device__ __forceinline__ double block_sum_array(const double *__restrict__ src
     }
     for (; i < n; i += kBlock) v += src[i];
     return block_sum(v, s_red);
+}
+
+struct PtrList {                      // destinations of a replicated store (one per shard)
+    void *p[kMaxShards];
+    int n;
+};
+
+// In-kernel reduction of the per-workgroup partials by the LAST workgroup to finish (more than one
+// shard only).  With one shard the consumer kernel sums the partials itself; with several, the shard's
+// partial has to exist as ONE number before the exchange, and a separate 1-block launch for that costs
+// a kernel boundary plus a launch on the iteration's critical path.  Protocol (cdna_hip_programming.md
+// section 5, split-K ticket in its write-through form): thread 0 of every workgroup stores its partial
+// with an agent-scope (sc1, write-through) store, drains it, then draws a ticket with a relaxed
+// agent-scope fetch_add; the workgroup that draws gridDim.x-1 reads ALL partials with agent-scope (sc1)
+// loads in the fixed order of block_sum_array -- the result is bit-identical to a separate reduction
+// launch -- stores it to slot `slot` of every destination and re-arms the ticket for the next launch.
+struct Finalize {
+    unsigned *ticket;                 // null: no in-kernel reduction
+    PtrList dst;
+    int slot;
+};
+
+// block_sum_array over partials other workgroups of THIS launch stored write-through: every load is an
+// agent-scope (sc1) load, same order as block_sum_array.
+__device__ __forceinline__ double block_sum_array_sc1(const double *src, int n, double *s_red)
+{
+    double v = 0.0;
+    int i = threadIdx.x < kBlock ? (int)threadIdx.x : n;      // wider workgroups: the extra waves add 0
+    auto ld = [&](int j) { return __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#pragma unroll 2
+    for (; i + 7 * kBlock < n; i += 8 * kBlock) {
+        const double a0 = ld(i), a1 = ld(i + kBlock), a2 = ld(i + 2 * kBlock), a3 = ld(i + 3 * kBlock);
+        const double a4 = ld(i + 4 * kBlock), a5 = ld(i + 5 * kBlock), a6 = ld(i + 6 * kBlock), a7 = ld(i + 7 * kBlock);
+        v += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    }
+    for (; i < n; i += kBlock) v += ld(i);
+    return block_sum(v, s_red);
+}
+
+// Store this workgroup's partial `t` (valid in thread 0) and, if `f.ticket` is set, let the last
+// workgroup of the launch reduce all of them (see Finalize).  Called by EVERY thread of the workgroup
+// (kBlock threads or more), outside divergent code.
+__device__ __forceinline__ void publish_partial(double t, double *partial, const Finalize &f, double *s_red /*[kWaves]*/)
+{
+    if (f.ticket == nullptr) {
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+        return;
+    }
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const double total = block_sum_array_sc1(partial, (int)gridDim.x, s_red);
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
+        __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <typename TA> struct MatVec;  // 16-byte vector of matrix elements
@@ -147,6 +209,7 @@ struct GemvArgs {
     uint64_t seg_end[2];
     int nseg;
     int accumulate;         // y[row] += ... instead of y[row] = ...
+    Finalize fin;           // in-kernel reduction of `partial` by the last workgroup (several shards)
 };
 
 // Fast path: n % (16/sizeof(TA)) == 0, A and p 16-byte aligned.
@@ -257,12 +320,13 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
         __syncthreads();
         if (lane == 0) s_red[wave] = dotp;
         __syncthreads();
+        double t = 0.0;
         if (tid == 0) {
-            double t = s_red[0];
+            t = s_red[0];
 #pragma unroll
             for (int w = 1; w < kWaves; w++) t += s_red[w];
-            a.partial[blockIdx.x] = t;
         }
+        publish_partial(t, a.partial, a.fin, s_red);
     }
 }
 
@@ -285,6 +349,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     __shared__ __attribute__((aligned(16))) TV s_p[TILE];
     __shared__ TV s_part[R][WAVES];
     __shared__ double s_dot[R];
+    __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
 
@@ -376,12 +441,13 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     }
     if (a.partial != nullptr) {
         __syncthreads();
+        double t = 0.0;
         if (tid == 0) {
-            double t = s_dot[0];
+            t = s_dot[0];
 #pragma unroll
             for (int r = 1; r < R; r++) t += s_dot[r];
-            a.partial[blockIdx.x] = t;
         }
+        publish_partial(t, a.partial, a.fin, s_red);
     }
 }
 
@@ -519,12 +585,13 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
         __syncthreads();
         if (lane == 0) s_red[wave] = dotp;
         __syncthreads();
+        double t = 0.0;
         if (tid == 0) {
-            double t = s_red[0];
+            t = s_red[0];
 #pragma unroll
             for (int w = 1; w < kWaves; w++) t += s_red[w];
-            a.partial[blockIdx.x] = t;
         }
+        publish_partial(t, a.partial, a.fin, s_red);
     }
 }
 
@@ -746,24 +813,21 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
     if (a.partial != nullptr) {
         if (lane == 0) s_red[wave] = dotp;
         __syncthreads();
+        double t = 0.0;
         if (threadIdx.x == 0) {
-            double t = s_red[0];
+            t = s_red[0];
 #pragma unroll
             for (int w = 1; w < kWaves; w++) t += s_red[w];
-            a.partial[blockIdx.x] = t;
         }
+        publish_partial(t, a.partial, a.fin, s_red);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // vector kernels
 // ---------------------------------------------------------------------------------------------
-struct PtrList {                      // destinations of a replicated store (one per shard)
-    void *p[kMaxShards];
-    int n;
-};
-
 // sum src[0..n) with one workgroup and store it at index `slot` of every destination array
+// (cg_init only: inside the iteration the producer kernels do this themselves, see Finalize)
 __global__ void __launch_bounds__(kBlock)
 finalize_sum_kernel(const double *__restrict__ src, int n, PtrList dst, int slot, const CgScalars *sc)
 {
@@ -817,7 +881,7 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
                  const TV *__restrict__ p_loc, const TV *__restrict__ Ap, TV *__restrict__ x,
-                 TV *__restrict__ r, uint64_t n_loc, double *__restrict__ partial)
+                 TV *__restrict__ r, uint64_t n_loc, double *__restrict__ partial, Finalize fin)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
@@ -833,10 +897,8 @@ update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
         acc += (double)ri * (double)ri;
     }
     double t = block_sum(acc, s_red);
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = t;
-        if (blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
+    publish_partial(t, partial, fin, s_red);
 }
 
 // rr' = r.r ; beta = rr'/rr ; if sqrt(rr'/bb) < tol: stop (p untouched) else p_slice = r + beta p
@@ -845,7 +907,7 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
                 const TV *__restrict__ r, const TV *__restrict__ p_loc, PtrList pdst, uint64_t row0,
-                uint64_t n_loc, volatile int *host_flags /* pinned host: [0]=iters [1]=stop */)
+                uint64_t n_loc, volatile int *host_flags /* pinned host: [0]=iters [1]=stopping iteration (0 = none) */)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
@@ -860,8 +922,8 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
         sc->iters = k;
         if (host_flags != nullptr) {
             host_flags[0] = k;
-            if (stop) host_flags[1] = 1;
-        }
+            if (stop) host_flags[1] = k;      // WHICH iteration stopped: the host compares it with the
+        }                                     // iteration whose completion it has awaited (lam_hip_cg_iterate)
     }
     if (stop) {
         // every workgroup reaches the same decision from the same bits; a workgroup that starts
@@ -959,8 +1021,8 @@ update_p_full_kernel(const double *__restrict__ red, int nred, CgScalars *sc, in
         sc->iters = k;
         if (host_flags != nullptr) {
             host_flags[0] = k;
-            if (stop) host_flags[1] = 1;
-        }
+            if (stop) host_flags[1] = k;      // WHICH iteration stopped: the host compares it with the
+        }                                     // iteration whose completion it has awaited (lam_hip_cg_iterate)
     }
     if (stop) {
         if (blockIdx.x == 0 && threadIdx.x == 0) sc->stop = 1;

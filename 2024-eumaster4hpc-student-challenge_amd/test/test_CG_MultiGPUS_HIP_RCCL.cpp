@@ -1,4 +1,6 @@
-// test_CG_MultiGPUS_HIP_RCCL.out -- one process per GPU, RCCL over xGMI.  Drop-in for the
+// test_CG_MultiGPUS_HIP_RCCL.out (also installed under the reference's target names
+// test_CG_MultiGPUS_CUDA_NCCL.out / test_CG_MultiGPUS_CUDA_MPI.out, test/CMakeLists.txt:19-29) -- one
+// process per GPU, RCCL over xGMI.  Drop-in for the
 // reference's getopt-style distributed drivers test_CG_MultiGPUS_CUDA_NCCL.out / _MPI.out /
 // test_CPU_MPI_OMP.out (/root/reference/challenge/main/test/test_CG_CPU_MPI_OMP.cpp:205-291 -- the
 // three differ only in the class name).  Same flags (-A -b | -s, -o -i -e -v -h), same defaults
@@ -21,7 +23,6 @@
 #include <unistd.h>
 
 #include "LAM.hpp"
-#include "lam_bootstrap.hpp"
 
 namespace
 {
@@ -56,13 +57,23 @@ struct Options {
 template <typename T>
 int run(const lam_bootstrap::Launch &L, const Options &o, int ndev);
 
+static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L);
+
 int main(int argc, char **argv)
 {
     lam_bootstrap::Launch L;
     if (!lam_bootstrap::init(&argc, &argv, L)) {
         fprintf(stderr, "bootstrap failed: %s\n", lam_hip_last_error(nullptr));
+        lam_bootstrap::finalize(L);
         return 1;
     }
+    const int rc = real_main(argc, argv, L);     // every exit path passes through finalize (MPI_Finalize)
+    lam_bootstrap::finalize(L);
+    return rc;
+}
+
+static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
+{
     Options o;
     const char *&matrix_file = o.matrix_file, *&rhs_file = o.rhs_file, *&sol_file = o.sol_file;
     int &max_iters = o.max_iters;
@@ -126,7 +137,6 @@ int main(int argc, char **argv)
         if (root) fprintf(stderr, "Unknown precision '%s' (f64, f32, bf16)\n", precision);
         return 1;
     }
-    lam_bootstrap::finalize(L);
     return rc;
 }
 
@@ -159,7 +169,7 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     if (mode_generate) ok = seed >= 0 ? cg.generate_random_system(rows, (uint64_t)seed, cond) : cg.generate_matrix(rows, rows);
     else ok = cg.load_matrix_from_file(matrix_file);
     const double t_load = std::chrono::duration<double>(clk::now() - t0).count();
-    if (!ok) {
+    if (!ok) {      // the loaders agree across ranks: a block that failed on one rank fails here on all
         if (root) fprintf(stderr, "Failed to read matrix\n");
         return 1;
     }

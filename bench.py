@@ -11,10 +11,16 @@ resident in HBM when the timed region starts.  Workload for every GPU count: BAS
 configs[2], N=65536 fp64 (34.4 GB, fits one MI355X) -- strong scaling, so the driver's 1/2/4/8
 series is one problem.  The matrix is the device-generated random dense SPD system
 (lam_hip_generate_random_spd, cond=1e6 so CG is still iterating at the end of the run).
-At N=1 GPU the line also carries the configs[1] (N=32768) figures under "also".
+At N=1 GPU the line also carries, under "also", configs[1] (N=32768) and the sizes the reference
+published numbers for (N=10000/20000/40000, TESTS/BEST_RESULTS:362-372) with the per-iteration cost
+outside the GEMV ("other_us").
 
-One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (gemv_coop_kernel):
-achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
+Under a launcher (RANK/WORLD_SIZE in the environment) every rank is one process on one GPU; the ranks
+find each other through the package's own socket rendezvous (no torch in the process: torch bundles a
+second ROCm runtime and a second RCCL) and the data path is RCCL inside liblam_hip.so.
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (its name comes from the
+library): achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
 the launch stream inside the timed steps.  `cpu_baseline` (rank 0, N=1 only) times the reference's
 own CPU driver (oracle/_ref, built from /root/reference in the build container) -- or, if that
 binary is missing, the oracle port -- on a bounded sample.
@@ -31,6 +37,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "2024-eumaster4hpc-student-challenge_amd"
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+ALSO_SIZES = (32768, 10000, 20000, 40000)
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library, which initialises the GPU before main(): a process in that
+    state must not start children (gpurun's exec guard), so the side runs are dropped."""
+    env = os.environ
+    return ("rocprofiler" in env.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in env)
+            or "rocprofiler" in env.get("HSA_TOOLS_LIB", ""))
 
 
 def cpu_baseline(sample_n, iters):
@@ -77,7 +92,7 @@ def cpu_baseline(sample_n, iters):
             "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
 
 
-def run_config(lam, make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False):
+def run_config(make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False):
     s = make_solver()
     s.generate_random_spd(n, seed, cond)
     s.generate_random_rhs(seed + 1)
@@ -96,6 +111,27 @@ def run_config(lam, make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6,
     return s, st, dt
 
 
+def side_run(args, n, symmetric=False):
+    """One extra configuration in a process of its own (before this process touches the GPU)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--order", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-also", "--no-cpu-baseline"] + (["--symmetric"] if symmetric else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def traffic_record(n, n_gpus):
+    """HBM bytes per launch of the dominant kernel from the PMC counters.  They cannot be collected inside
+    an un-profiled run, so this is the value of the committed rocprofv3 passes (profiles/traffic.json), tagged
+    with where it came from."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        e = json.load(open(tpath))[f"n{n}_p{n_gpus}"]
+        return e["hbm_bytes_per_launch"], {"measured_in_this_run": False, "file": "profiles/traffic.json", "counters": e.get("source"),
+                                           "library_commit": e.get("commit"), "kernel": e.get("kernel")}
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +141,7 @@ def main():
     # abbreviation of its --nnodes/--nproc-per-node/... options even after the script name
     ap.add_argument("--n", "--order", dest="n", type=int, default=65536, help="matrix order (default: BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] (N=32768) and symmetric-option runs")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra sizes and the symmetric-option run")
     ap.add_argument("--symmetric", action="store_true",
                     help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
@@ -114,49 +150,44 @@ def main():
 
     # the host driver on these nodes only supports dmabuf IPC; RCCL across processes needs this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or "RANK" in os.environ
-    if use_dist:
-        # Import order matters: torch bundles its own ROCm runtime libraries under the same sonames as
-        # /opt/rocm's.  torch first, then liblam_hip.so (which then binds to the already loaded ones)
-        # is the torch-extension order and is clean; the reverse order aborts at interpreter exit.
-        import torch  # noqa: F401
     lam = importlib.import_module(PKG)
     lam.lib()
+    use_dist = lam.launched_with_ranks()
+    rdzv = lam.Rendezvous() if use_dist else None
+    world = rdzv.size if rdzv else 1
+    rank = rdzv.rank if rdzv else 0
+    profiled = under_profiler()
+    solo = rank == 0 and not use_dist and max(1, args.gpus) == 1
 
-    # The CPU baseline runs a child process, so it goes FIRST: nothing has touched the GPU yet
-    # (a process that has initialised the GPU must not fork+exec on this pool).
+    # Child processes go FIRST: nothing has touched the GPU yet (a process that has initialised the GPU
+    # must not fork+exec on this pool), and never under a profiler (its tool library initialises the GPU
+    # before main()).
     cb = None
-    if rank == 0 and world == 1 and max(1, args.gpus) == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline and not profiled:
         cb = cpu_baseline(args.cpu_sample_n, args.cpu_sample_iters)
 
-    # configs[1] (N=32768) goes to a child process of its own, also before this process touches the
-    # GPU: measured in-process after the 34 GB run its GEMV is ~2 % slower (allocation history), so
-    # each configuration gets a fresh address space.
+    # Other sizes: configs[1] (N=32768) and the reference's published sizes, one process each (a fresh
+    # address space per configuration, DESIGN.md section 6 "allocation history").
     also = None
-    if rank == 0 and not use_dist and max(1, args.gpus) == 1 and not args.no_also and args.n != 32768:
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--order", "32768", "--steps", str(args.steps),
-                                "--warmup", str(args.warmup), "--no-also", "--no-cpu-baseline"],
-                               capture_output=True, text=True, timeout=900)
-            d = json.loads(r.stdout.strip().splitlines()[-1])
-            also = {"workload": "N=32768 fp64 (BASELINE configs[1]), same generator, own process", "value": d["value"],
-                    "ms_per_step": d["ms_per_step"], "gemv_ms": d["gemv_ms"], "gemv_gbps": d["gemv_gbps_per_gpu"],
-                    "roofline_frac": d["roofline"]["frac"]}
-        except Exception as e:   # noqa: BLE001
-            sys.stderr.write(f"[bench] configs[1] side run failed: {e}\n")
+    if solo and not args.no_also and not profiled and not args.symmetric:
+        also = []
+        for n_also in ALSO_SIZES:
+            if n_also == args.n:
+                continue
+            try:
+                d = side_run(args, n_also)
+                also.append({"n": n_also, "value": d["value"], "ms_per_step": d["ms_per_step"], "gemv_ms": d["gemv_ms"],
+                             "other_us": (d["ms_per_step"] - d["gemv_ms"]) * 1e3, "gemv_gbps": d["gemv_gbps_per_gpu"],
+                             "roofline_frac": d["roofline"]["frac"], "kernel": d["roofline"]["kernel"]})
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write(f"[bench] side run N={n_also} failed: {e}\n")
 
     # Opt-in "symmetric" product (reads only the upper triangle; 1 GPU), reported beside the headline,
-    # never as it: own process for the same reason as above.
+    # never as it.
     sym = None
-    if rank == 0 and not use_dist and max(1, args.gpus) == 1 and not args.no_also and not args.symmetric:
+    if solo and not args.no_also and not profiled and not args.symmetric:
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--order", str(args.n), "--steps", str(args.steps),
-                                "--warmup", str(args.warmup), "--no-also", "--no-cpu-baseline", "--symmetric"],
-                               capture_output=True, text=True, timeout=900)
-            d = json.loads(r.stdout.strip().splitlines()[-1])
+            d = side_run(args, args.n, symmetric=True)
             sym = {"what": "lam_hip_set_option('symmetric', 1): the product reads only the upper triangle of the SPD matrix "
                            "(two-pass, deterministic); same problem, own process; NOT the headline (different algorithm, "
                            "single GPU only)", "value": d["value"], "ms_per_step": d["ms_per_step"],
@@ -164,29 +195,16 @@ def main():
         except Exception as e:   # noqa: BLE001
             sys.stderr.write(f"[bench] symmetric-option side run failed: {e}\n")
 
-    dist = None
     if use_dist:
-        # torch.distributed is control plane only (rendezvous, barrier, max over ranks); the data
-        # path collectives are RCCL calls inside liblam_hip.so on its own stream.
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # single node: the container hostname may not resolve
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        uid = [lam.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        uid = uid[0]
-
+        uid = rdzv.broadcast(lam.get_unique_id() if rank == 0 else b"")
         ndev = lam.device_count()          # counting devices does not initialise the GPU
 
         def make_solver():
-            return lam.Solver(lam.F64, rank=rank, nranks=world, device_id=local_rank % max(1, ndev), unique_id=uid)
+            return lam.Solver(lam.F64, rank=rank, nranks=world, device_id=rdzv.local_rank % max(1, ndev), unique_id=uid)
 
-        def barrier():
-            dist.barrier()
+        barrier = rdzv.barrier
         n_gpus = world
-        parallelism = f"row-sharded x{world}, 1 process/GPU, RCCL all-reduce x2 + all-gather(p) per iteration"
+        parallelism = f"row-sharded x{world}, 1 process/GPU, RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration"
     else:
         n_gpus = max(1, args.gpus)
 
@@ -200,26 +218,25 @@ def main():
         parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores"
 
     n = args.n
-    s, st, dt = run_config(lam, make_solver, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
+    s, st, dt = run_config(make_solver, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
+    kernel_name = s.gemv_kernel_name()
 
     def max_over_ranks(dt_, st_):
-        if dist is None:
+        if rdzv is None:
             return dt_, st_
-        import torch
-        t = torch.tensor([dt_, st_["t_gemv"]], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        st_["t_gemv"] = float(t[1])
-        return float(t[0]), st_
+        dt_, st_["t_gemv"] = rdzv.max([dt_, st_["t_gemv"]])
+        return dt_, st_
 
     dt, st = max_over_ranks(dt, st)
     true_res = s.true_residual()
     exchange_modes = None
-    if dist is not None and (world > 1 or os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0")):
+    if rdzv is not None and (world > 1 or os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0")):
         # Same problem, same context, the other exchange: ONE all-gather of [Ap slice | p.Ap partial] per
-        # iteration and redundant full-length r/p updates instead of all-reduce x2 + all-gather(p).
+        # iteration and redundant full-length r/p updates instead of all-gather x2 + all-gather(p).
         # Both are product paths under the same parity tests; the headline is the faster one.
-        exchange_modes = {"allreduce_x2+allgather_p": {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+        exchange_modes = {"allgather_x2+allgather_p": {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                                                        "gemv_ms": st["t_gemv"] * 1e3, "rel_residual_true": true_res}}
+
         def timed(label, **opts):
             for k_, v_ in opts.items():
                 s.set_option(k_, v_)
@@ -240,26 +257,18 @@ def main():
         # the headline is the fastest of the three
         base = f"row-sharded x{world}, 1 process/GPU, "
         runs = [(dt, st, true_res, parallelism)]
-        runs.append(timed("allreduce_x2+allgather_p, no overlap", exchange=0, overlap=0) +
-                    (base + "RCCL all-reduce x2 + all-gather(p) per iteration on one stream (no overlap)",))
+        runs.append(timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0) +
+                    (base + "RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration on one stream (no overlap)",))
         runs.append(timed("allgather_Ap", exchange=1, overlap=1) +
                     (base + "ONE RCCL all-gather of [Ap slice | p.Ap partial] per iteration (full-length r, p per rank)",))
         dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])
+    n_coll = s.get_option("collectives_enqueued")
     s.close()
 
     ms_per_step = dt / args.steps * 1e3
     gemv_bytes = st["gemv_bytes"]                 # algorithmic bytes of ONE launch on one GPU
     achieved = gemv_bytes / st["t_gemv"] / 1e9 if st["t_gemv"] > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"n{n}_p{n_gpus}"
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    traffic, traffic_src = traffic_record(n, n_gpus)
 
     out = {
         "metric": "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
@@ -271,17 +280,23 @@ def main():
                    "n": n, "parallelism": parallelism,
                    "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
         "gemv_ms": st["t_gemv"] * 1e3,
+        "other_us": (ms_per_step - st["t_gemv"] * 1e3) * 1e3,
         "gemv_gbps_per_gpu": achieved,
         "gemv_gbps_aggregate": achieved * n_gpus,
         "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res, "rccl_init_s": st.get("t_comm_init", 0.0),
         **({"exchange_modes": exchange_modes} if exchange_modes else {}),
-        "roofline": {"bound": "hbm", "kernel": "gemv_coop_kernel<double,double,R=2,TILE=4096,nt,unroll4,waves4>",
+        "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": gemv_bytes},
+        "host_plumbing": {"torch_imported": "torch" in sys.modules,
+                          "rendezvous": "package socket rendezvous (_rendezvous.py)" if rdzv else None,
+                          "rccl_version": lam.rccl_version() if rdzv else None,
+                          "rccl_calls_enqueued_rank0": n_coll if rdzv else None,
+                          "profiler_detected": profiled},
     }
 
-    if also is not None:
+    if also:
         out["also"] = also
     if sym is not None:
         sym["speedup_vs_headline"] = sym["value"] / out["value"]
@@ -289,18 +304,17 @@ def main():
     if args.symmetric:
         out["config"]["workload"] += "; option symmetric=1 (upper-triangle product)"
         out["roofline"] = None     # the GEMV roofline does not describe this algorithm
-    if rank == 0 and n_gpus == 1 and world == 1:
-        if cb is not None:
-            # same unit as `value`, scaled to the workload's N (bytes per iteration scale with N^2)
-            cb["value_at_sample_n"] = cb["value"]
-            cb["value"] = cb["value"] * (cb["sample_n"] / float(n)) ** 2
-            cb["sample"] += f"; value = measured it/s x ({cb['sample_n']}/{n})^2 to the workload's N"
-            out["cpu_baseline"] = cb
+    if solo and cb is not None:
+        # same unit as `value`, scaled to the workload's N (bytes per iteration scale with N^2)
+        cb["value_at_sample_n"] = cb["value"]
+        cb["value"] = cb["value"] * (cb["sample_n"] / float(n)) ** 2
+        cb["sample"] += f"; value = measured it/s x ({cb['sample_n']}/{n})^2 to the workload's N"
+        out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
 
 
 if __name__ == "__main__":

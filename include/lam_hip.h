@@ -79,7 +79,7 @@ int lam_hip_device_count(int *count);
 int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device_ids);
 
 /* One process per GPU: this process owns shard `rank` of `nranks` on `device_id`; the per
- * iteration exchange is RCCL (all-gather of p, all-reduce of the two dot products).
+ * iteration exchange is RCCL (all-gather of p, and of the ranks' partial dot products).
  * `unique_id` = LAM_HIP_UNIQUE_ID_BYTES bytes obtained from lam_hip_get_unique_id() on one rank
  * and distributed by the caller (MPI_Bcast, torch.distributed, a file ...), exactly the
  * bootstrap of ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:306-334 (ncclGetUniqueId + MPI_Bcast +
@@ -176,9 +176,24 @@ int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double bet
  * verify the precondition of option "symmetric".  No reference counterpart. */
 int lam_hip_check_symmetry(lam_hip_ctx *ctx, double *max_abs_asymmetry);
 
+/* Agreement across ranks (collective in rank mode, identity otherwise): *global_ok = 1 iff every rank passed
+ * local_ok != 0.  Lets a step that can fail on ONE rank (reading its row block from a file) fail on ALL of
+ * them instead of leaving the others waiting in the next collective.  The reference has MPI_Abort on file
+ * errors for this (ConjugateGradient_CPU_MPI_OMP.hpp:325-329). */
+int lam_hip_all_ok(lam_hip_ctx *ctx, int local_ok, int *global_ok);
+
+/* Version of the RCCL library this process is bound to (ncclGetVersion; the reference links NCCL 2.18.3,
+ * LAM/CMakeLists.txt:11) -- bench.py records it next to its multi-GPU numbers. */
+int lam_hip_rccl_version(int *version);
+/* Name of the GEMV kernel instantiation the context launches for its current dtype / N / options, e.g.
+ * "gemv_coop_kernel<double,double,R=2,TILE=4096,NT=true,UNROLL=4,WAVES=4>" (what a profiler shows).
+ * No reference counterpart (the reference has one gemv kernel, NCCL.cu:185-226). */
+int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
+
 /* ---- options --------------------------------------------------------------------------------- */
 /* name/value pairs; unknown names -> LAM_HIP_EINVAL.
- *   "exchange"      rank mode only.  0 (default): per iteration ncclAllReduce(p.Ap), ncclAllReduce(r.r),
+ *   "exchange"      rank mode only.  0 (default): per iteration an 8-byte-per-rank ncclAllGather for p.Ap and for
+ *                   r.r (summed in rank order by the consumer kernel: deterministic, identical on every rank) and
  *                   ncclAllGather(p slices) -- sliced x, r, Ap, replicated p.  1: ONE ncclAllGather of
  *                   [Ap slice | p.Ap partial] per iteration, r and p kept full-length on every rank and
  *                   updated redundantly (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505); needs
@@ -189,6 +204,12 @@ int lam_hip_check_symmetry(lam_hip_ctx *ctx, double *max_abs_asymmetry);
  *                   anyway; lam_hip_check_symmetry verifies it) -- about half the HBM traffic per iteration.
  *                   0 (default) = the reference's general row-partitioned GEMV.  "symmetric_effective" tells
  *                   whether the current context can use it.
+ *   "finalize"      several shards: 1 (default) = the last workgroup of the GEMV / update kernel reduces the
+ *                   shard's partial dot product inside the launch (3 launches per iteration for any shard
+ *                   count); 0 = separate 1-workgroup reduction launches (5 per iteration; A/B measurements).
+ *   "upload_staging" lam_hip_upload_rows: 1 = copy through two pinned staging buffers (host memcpy overlapped
+ *                   with the DMA); 0 (default) = hand the caller's pages to the runtime directly.
+ *   "collectives_enqueued" (get only) RCCL calls this context has enqueued so far -- equal on all ranks.
  *   "overlap"       rank mode, exchange 0: 1 (default) puts the all-gather of p on a second stream under the
  *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.
  *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype; 0..22 = tuning shapes

@@ -34,3 +34,30 @@ def golden():
     import json
     with open(os.path.join(GOLDEN, "golden.json")) as f:
         return json.load(f)
+
+
+MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
+
+
+@pytest.fixture(scope="session")
+def mock_async():
+    """Stream-ordered RCCL test double (tests/mock_rccl/mock_rccl_async.hip), built on demand."""
+    import subprocess
+    lib, src = os.path.join(MOCK_DIR, "libmock_rccl_async.so"), os.path.join(MOCK_DIR, "mock_rccl_async.hip")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", src,
+                        "-o", lib, "-lrt"], check=True)
+    return lib
+
+
+@pytest.fixture(scope="session")
+def mock_mp_lib():
+    """Host-synchronous multi-process RCCL test double (tests/mock_rccl/mock_rccl_mp.cpp)."""
+    import subprocess
+    lib, src = os.path.join(MOCK_DIR, "libmock_rccl_mp.so"), os.path.join(MOCK_DIR, "mock_rccl_mp.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        # g++ and NOT linked against libamdhip64: the HIP symbols bind at first use to the runtime the
+        # process already holds (liblam_hip.so's) instead of dragging in a second one
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        src, "-o", lib, "-lrt", "-lpthread"], check=True)
+    return lib

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""Runs P rank-mode contexts as P threads of this process (all on GPU 0) on top of the mock RCCL that
-is LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl.cpp).  Prints one JSON line.
-usage: run_ranks.py P N mode [overlap [exchange]]   with mode in {tridiag, spd}"""
-import importlib, json, os, sys, threading
+"""Runs P rank-mode contexts as P threads of this process (all on GPU 0) on top of a mock RCCL that is
+LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl_async.hip: stream-ordered, nothing
+synchronises hosts or streams -- the semantics of the real library).  Prints one JSON line.
+
+usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1] [--finalize 0|1] [--iters K] [--tol T]
+                             [--chunk C]    with mode in {tridiag, spd}
+--chunk C runs the solve as repeated lam_hip_cg_iterate(C) calls (the stop has to be noticed across
+calls, and every rank must leave the loop after the same call)."""
+import argparse, importlib, json, os, sys, threading
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,33 +16,58 @@ lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 
 
 def main():
-    P, n, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-    overlap = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    exchange = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    ap = argparse.ArgumentParser()
+    ap.add_argument("P", type=int)
+    ap.add_argument("n", type=int)
+    ap.add_argument("mode", choices=["tridiag", "spd"])
+    ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--exchange", type=int, default=0)
+    ap.add_argument("--finalize", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--tol", type=float, default=None)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cond", type=float, default=200.0)
+    ap.add_argument("--no-single", action="store_true", help="skip the single-shard comparison run")
+    a = ap.parse_args()
+    P, n, mode = a.P, a.n, a.mode
+    tol = a.tol if a.tol is not None else (1e-9 if mode == "tridiag" else 1e-10)
+    iters = a.iters if a.iters is not None else (10000 if mode == "tridiag" else 2000)
     uid = lam.get_unique_id()
-    assert uid.startswith(b"mock-rccl-"), "the mock is not in front of librccl"
+    assert uid.startswith(b"/lam_mock_") or uid.startswith(b"mock-rccl-"), "the mock is not in front of librccl"
     out = [None] * P
     errs = []
+    xprobe = np.arange(n, dtype=np.float64) / n
+
+    def setup(s):
+        if mode == "tridiag":
+            s.generate_matrix(n)
+            s.generate_rhs()
+        else:
+            s.generate_random_spd(n, 99, a.cond)
+            s.generate_random_rhs(100)
 
     def rank_main(r):
         try:
             with lam.Solver(lam.F64, rank=r, nranks=P, device_id=0, unique_id=uid) as s:
-                if mode == "tridiag":
-                    s.generate_matrix(n)
-                    s.generate_rhs()
-                    tol, iters = 1e-9, 10000
+                setup(s)
+                s.set_option("overlap", a.overlap)
+                s.set_option("exchange", a.exchange)
+                s.set_option("finalize", a.finalize)
+                if a.chunk > 0:
+                    s.cg_init()
+                    done, conv, calls = 0, False, 0
+                    while done < iters and not conv:
+                        st = s.cg_iterate(min(a.chunk, iters - done), tol)
+                        done += a.chunk
+                        calls += 1
+                        conv = bool(st["converged"])
                 else:
-                    s.generate_random_spd(n, 99, 200.0)
-                    s.generate_random_rhs(100)
-                    tol, iters = 1e-10, 2000
-                s.set_option("overlap", overlap)
-                s.set_option("exchange", exchange)
-                conv = s.solve(iters, tol)
+                    conv, calls = s.solve(iters, tol), 1
                 x = s.solution()                 # collective
                 res = s.true_residual()          # collective
-                y = s.gemv(np.arange(n, dtype=np.float64) / n)   # collective
+                y = s.gemv(xprobe)               # collective
                 out[r] = dict(conv=conv, iters=s.stats["num_iters"], err=s.stats["rel_err"], x=x, res=res, y=y,
-                              part=s.partition(r))
+                              part=s.partition(r), ncoll=s.get_option("collectives_enqueued"), calls=calls)
         except Exception as e:                   # noqa: BLE001
             errs.append(f"rank {r}: {e!r}")
 
@@ -45,26 +75,28 @@ def main():
     for t in th:
         t.start()
     for t in th:
-        t.join(240)
+        t.join(300)
     if errs or any(o is None for o in out):
-        print(json.dumps({"error": errs or "a rank did not finish"}))
+        print(json.dumps({"error": errs or "a rank did not finish",
+                          "ncoll": [o["ncoll"] if o else None for o in out]}))
         sys.exit(1)
-    # reference: the same system on one shard, no RCCL
-    with lam.Solver(lam.F64) as s:
-        if mode == "tridiag":
-            s.generate_matrix(n); s.generate_rhs(); s.solve(10000, 1e-9)
-        else:
-            s.generate_random_spd(n, 99, 200.0); s.generate_random_rhs(100); s.solve(2000, 1e-10)
-        x1, it1 = s.solution(), s.stats["num_iters"]
-        y1 = s.gemv(np.arange(n, dtype=np.float64) / n)
-    same = all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"] and o["err"] == out[0]["err"]
-               and np.array_equal(out[0]["y"], o["y"]) for o in out)
-    print(json.dumps({
-        "P": P, "n": n, "ranks_identical": bool(same), "iters": out[0]["iters"], "iters_single": it1,
-        "converged": bool(out[0]["conv"]), "true_residual": out[0]["res"], "rel_err": out[0]["err"],
-        "x_vs_single": float(np.linalg.norm(out[0]["x"] - x1) / np.linalg.norm(x1)),
-        "gemv_vs_single": float(np.max(np.abs(out[0]["y"] - y1)) / np.max(np.abs(y1))),
-        "partition": [list(o["part"]) for o in out]}))
+    res = {
+        "P": P, "n": n, "iters": out[0]["iters"], "converged": bool(out[0]["conv"]), "true_residual": out[0]["res"],
+        "rel_err": out[0]["err"], "partition": [list(o["part"]) for o in out],
+        "collectives_enqueued": [o["ncoll"] for o in out], "iterate_calls": [o["calls"] for o in out],
+        "ranks_identical": bool(all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"]
+                                    and o["err"] == out[0]["err"] and np.array_equal(out[0]["y"], o["y"]) for o in out)),
+    }
+    if not a.no_single:
+        # the same system on one shard, no RCCL
+        with lam.Solver(lam.F64) as s:
+            setup(s)
+            s.solve(iters, tol)
+            x1, it1 = s.solution(), s.stats["num_iters"]
+            y1 = s.gemv(xprobe)
+        res.update(iters_single=it1, x_vs_single=float(np.linalg.norm(out[0]["x"] - x1) / np.linalg.norm(x1)),
+                   gemv_vs_single=float(np.max(np.abs(out[0]["y"] - y1)) / np.max(np.abs(y1))))
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":

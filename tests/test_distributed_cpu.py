@@ -1,9 +1,9 @@
 """world_size-2 (and 3) `gloo` test of the N>1 protocol, on CPU.
 
 The HIP kernels need a GPU, so this test runs the *exchange protocol* of the rank mode
-(csrc/lam_hip.hip: row partition -> local GEMV on the own row block -> all-reduce of the partial
-p.Ap -> x, r updates on the own slice -> all-reduce of the partial r.r -> p update on the own slice
--> all-gather of p) with the product's partition function (lam_hip_partition through the C ABI) and
+(csrc/lam_hip.hip: row partition -> local GEMV on the own row block -> exchange of the partial
+p.Ap (summed in rank order) -> x, r updates on the own slice -> exchange of the partial r.r -> p update
+on the own slice -> all-gather of p) with the product's partition function (lam_hip_partition through the C ABI) and
 torch.distributed collectives, the oracle's operators standing in for the device kernels.  It pins
 that the sharded recurrence reproduces the reference's MPI path: bit-identical to the emulated-rank
 oracle at P=2 (a+b is order-independent), to rounding at P=3."""
@@ -16,15 +16,13 @@ import pytest
 from conftest import ROOT, PKG_NAME
 
 
-def _worker(rank, world, port, n, max_iters, tol, outdir):
-    import importlib
+def _worker(rank, world, port, n, max_iters, tol, outdir, parts):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lam = importlib.import_module(PKG_NAME)
     from oracle import pyoracle as o
 
     # control plane used by bench.py: rank 0's opaque id reaches everyone
@@ -34,8 +32,7 @@ def _worker(rank, world, port, n, max_iters, tol, outdir):
     dist.all_gather_object(ids, blob[0])
     assert all(i == ids[0] for i in ids) and len(ids[0]) == 128
 
-    row0, nrows = lam.partition(n, world, rank)
-    parts = [lam.partition(n, world, q) for q in range(world)]
+    row0, nrows = parts[rank]                          # the product's partition (computed by the parent)
     A_loc = o.tridiag(n, row0, nrows)                 # generate mode: rows by global index
     rng = np.random.default_rng(5)
     b = rng.uniform(-1, 1, n)                          # same on every rank (seeded)
@@ -84,14 +81,17 @@ def _worker(rank, world, port, n, max_iters, tol, outdir):
 
 @pytest.mark.parametrize("world,n", [(2, 256), (3, 301)])
 def test_sharded_protocol_matches_reference_mpi_path(world, n, oracle, tmp_path):
-    # plain multiprocessing with the spawn context: the parent (pytest) must not import torch after
-    # liblam_hip.so has been loaded by another test (load order: see bench.py); the workers import
-    # torch first, then the package.
+    # The row partition comes from the product (lam_hip_partition through the C ABI) in THIS process; the
+    # gloo workers are separate processes that hold torch and the oracle but never liblam_hip.so -- no
+    # process maps torch's bundled ROCm runtime and /opt/rocm's together.
+    import importlib
     import multiprocessing
+    lam = importlib.import_module(PKG_NAME)
+    parts = [lam.partition(n, world, q) for q in range(world)]
     ctx = multiprocessing.get_context("spawn")
     port = 29600 + world + (os.getpid() % 200)
     max_iters, tol = 10000, 1e-9
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, max_iters, tol, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, max_iters, tol, str(tmp_path), parts)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:

@@ -100,8 +100,9 @@ def test_driver_exit_codes(tmp_path, golden):
 
 
 def test_rank_mode_collectives_single_rank(lam, oracle, monkeypatch):
-    """LAM_HIP_FORCE_RCCL=1 runs every RCCL call of the one-process-per-GPU path (ncclAllReduce x2,
-    ncclAllGather / grouped ncclBroadcast per iteration, the gathers of x) on a 1-rank communicator.
+    """LAM_HIP_FORCE_RCCL=1 runs every RCCL call of the one-process-per-GPU path (the 8-byte ncclAllGather
+    x2 + ncclAllGather / grouped ncclBroadcast of p per iteration, the gathers of x, the all-reduce of the
+    residual check) on a 1-rank communicator of the REAL library.
     The result must be bit-identical to the plain single-shard path (same reduction order)."""
     n = 1000
     rng = np.random.default_rng(3)
@@ -145,6 +146,97 @@ def test_mpi_bootstrapped_driver_single_rank(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     f = _csv(r.stdout)
     assert f[0] == "4096" and int(f[7]) == 16 and abs(float(f[8]) / 0.000368282 - 1) < 1e-5
+
+
+def _mock_env(kind, mock_mp_lib, mock_async, tmp_path):
+    lib = mock_mp_lib if kind == "mp" else mock_async
+    return lib, {"GPU_MAX_HW_QUEUES": "8", "MOCK_RCCL_STATS_FILE": str(tmp_path / "mock_stats.jsonl"),
+                 "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def _skip_if_no_ipc(r):
+    if "HIP IPC is not available" in r.stderr or "hipIpcOpenMemHandle failed" in r.stderr:
+        pytest.skip("HIP IPC between processes is not available on this box")
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("kind", ["mp", "async"])
+def test_mpi_bootstrapped_driver_multi_rank(tmp_path, mock_mp_lib, mock_async, nranks, kind):
+    """`mpiexec -n P test_CG_MultiGPUS_HIP_RCCL_mpi.out`: MPI_Init + MPI_Bcast of the unique id + one rank per
+    process, the launch of the reference's NCCL variant (NCCL.cu:320-327; TESTS/GPU_SCRIPTS use srun -n).
+    All ranks share GPU 0, so librccl is replaced by a test double: "mp" = host-synchronous, "async" =
+    stream-ordered with the slot ring shared through HIP IPC.  Generate mode, run to convergence: the
+    known answer (2048 iterations at N=4096) and a stop that every rank must act on in the same iteration."""
+    exe = os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP_RCCL_mpi.out")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("MPI driver not built (make mpi)")
+    lib, env = _mock_env(kind, mock_mp_lib, mock_async, tmp_path)
+    genv = ["-genv", "LD_PRELOAD", lib]
+    for k, v in env.items():
+        genv += ["-genv", k, v]
+    sol = tmp_path / "sol.bin"
+    r = _run([mpiexec, "-n", str(nranks)] + genv + [exe, "-s", "4096", "-o", str(sol)])
+    _skip_if_no_ipc(r)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = _csv(r.stdout)
+    assert f[0] == "4096" and f[1] == str(nranks) and int(f[7]) == 2048 and float(f[8]) < 1e-9, f
+    x = np.fromfile(sol, dtype=np.float64, offset=16)
+    A_x = 2 * x; A_x[1:] += x[:-1]; A_x[:-1] += x[1:]                  # tridiag(1,2,1) x
+    assert np.linalg.norm(A_x - 1.0) / np.sqrt(4096) < 1e-8
+    if kind == "async":
+        import json
+        lines = [json.loads(l) for l in open(tmp_path / "mock_stats.jsonl")]
+        assert len(lines) == nranks and all(l["abort"] == 0 for l in lines) and len({l["calls"] for l in lines}) == 1, lines
+
+
+@pytest.mark.parametrize("exe_name", ["test_CG_MultiGPUS_HIP_RCCL.out", "test_CG_MultiGPUS_CUDA_NCCL.out"])
+def test_env_launched_driver_multi_rank(tmp_path, mock_mp_lib, golden, oracle, exe_name):
+    """No MPI: P processes that only get RANK / WORLD_SIZE / LOCAL_RANK from their launcher (what
+    `torchrun --no-python`, srun or mpiexec export) and agree on the unique id through the rendezvous file.
+    File mode: every rank reads its own row block; the solution must match the reference's golden x.
+    Run under the reference's executable name too (Makefile ALIASES)."""
+    import json
+    g = next(x for x in golden["file_mode"] if x["n"] == 256)
+    P = 3
+    sol = tmp_path / "sol.bin"
+    procs = []
+    for rank in range(P):
+        e = dict(os.environ, LD_PRELOAD=mock_mp_lib, RANK=str(rank), WORLD_SIZE=str(P), LOCAL_RANK="0",
+                 LAM_RCCL_ID_FILE=str(tmp_path / "id"))
+        procs.append(subprocess.Popen([os.path.join(TEST_DIR, exe_name), "-A", os.path.join(GOLDEN, g["name"] + ".matrix.bin"),
+                                       "-b", os.path.join(GOLDEN, g["name"] + ".rhs.bin"), "-o", str(sol), "-e", repr(g["tol"])],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    f = _csv(outs[0][0])
+    assert int(f[0]) == g["n"] and f[1] == str(P)
+    assert abs(int(f[7]) - g["iters_printed"]) <= max(3, 0.02 * g["iters_printed"]) and float(f[8]) < g["tol"]
+    assert all(o[0].strip() == "" for o in outs[1:])                    # only rank 0 prints the CSV
+    x = oracle.read_bin(str(sol)).reshape(-1)
+    x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    assert not os.path.exists(tmp_path / "id")                          # rank 0 removed the rendezvous file
+
+
+def test_rank_local_load_failure_fails_on_every_rank(tmp_path, mock_mp_lib, golden):
+    """One rank cannot read the matrix: the loaders agree across ranks (lam_hip_all_ok), so EVERY rank
+    leaves with exit code 1 instead of the others waiting in the first collective of the solve."""
+    g = next(x for x in golden["file_mode"] if x["n"] == 128)
+    good = os.path.join(GOLDEN, g["name"] + ".matrix.bin")
+    # rank 1 is pointed at a truncated copy: same header, the tail of its row block is missing
+    bad = tmp_path / "truncated.bin"
+    data = open(good, "rb").read()
+    bad.write_bytes(data[: len(data) - 4096])
+    procs = []
+    for rank in range(2):
+        e = dict(os.environ, LD_PRELOAD=mock_mp_lib, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0",
+                 LAM_RCCL_ID_FILE=str(tmp_path / "id"))
+        procs.append(subprocess.Popen([RCCL_EXE, "-A", str(bad) if rank == 1 else good, "-b",
+                                       os.path.join(GOLDEN, g["name"] + ".rhs.bin"), "-o", str(tmp_path / "s.bin")],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [1, 1], outs
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 2e-4), ("bf16", 2e-4)])

@@ -1,12 +1,18 @@
 """Rank mode (one context per GPU rank, RCCL exchange) with P > 1 on a ONE-GPU box.
 
-RCCL refuses two ranks on one device, so the P ranks run as P threads of one process on GPU 0 with
-tests/mock_rccl/libmock_rccl.so LD_PRELOADed in front of librccl.so: a host-synchronous stand-in
-that implements the six collectives' data semantics and verifies that every rank issues the same
-call sequence with the same counts.  What this pins down is liblam_hip.so's own rank-mode logic:
-partition by rank, in-place all-gather offsets, the grouped broadcasts of the uneven split, the
-own-slice GEMV panel + accumulate (overlap path), identical stop decisions, the collective gathers
-of x.  (The real RCCL calls are exercised with a 1-rank communicator in test_gpu_drivers.py.)"""
+RCCL refuses two ranks on one device, so the P ranks run as P threads of one process (or P processes)
+on GPU 0 with a test double LD_PRELOADed in front of librccl.so:
+
+* tests/mock_rccl/mock_rccl_async.hip -- STREAM-ORDERED: every collective is a kernel enqueued on the
+  caller's stream that publishes into a shared slot ring and spins on the peers' generation counters;
+  nothing synchronises the hosts or a stream.  These are the semantics real RCCL has, so what is pinned
+  down is what will hold on 8 GPUs: every rank enqueues the SAME sequence of collectives whatever the
+  relative speed of its host and its GPU (the stop protocol), the in-place all-gather offsets, the
+  grouped broadcasts of the uneven split, the own-slice GEMV panel running beside the all-gather on a
+  second stream of the same communicator, identical stop decisions, the collective gathers of x.
+* tests/mock_rccl/mock_rccl_mp.cpp -- host-synchronous, multi-process: the driver's torchrun command.
+
+(The real RCCL calls are exercised with a 1-rank communicator in test_gpu_drivers.py.)"""
 import json
 import os
 import subprocess
@@ -18,15 +24,46 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
-MOCK = os.path.join(MOCK_DIR, "libmock_rccl.so")
 
 
-@pytest.fixture(scope="module")
-def mock_lib():
-    src = os.path.join(MOCK_DIR, "mock_rccl.cpp")
-    if not os.path.exists(MOCK) or os.path.getmtime(MOCK) < os.path.getmtime(src):
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", MOCK], check=True)
-    return MOCK
+def _env(mock, P, tmp_path, **extra):
+    stats = os.path.join(str(tmp_path), "mock_stats.jsonl")
+    # a kernel that waits for a peer must never share a hardware queue with the kernel it waits for
+    env = dict(os.environ, LD_PRELOAD=mock, GPU_MAX_HW_QUEUES=str(2 * P + 4), MOCK_RCCL_STATS_FILE=stats,
+               MOCK_RCCL_TIMEOUT_MS="20000")
+    env.update({k: str(v) for k, v in extra.items()})
+    return env, stats
+
+
+def _run(mock, tmp_path, P, n, mode, *opts, env_extra=None, expect_ok=True):
+    env, stats = _env(mock, P, tmp_path, **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(MOCK_DIR, "run_ranks.py"), str(P), str(n), mode, *map(str, opts)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(l) for l in open(stats)] if os.path.exists(stats) else []
+    if expect_ok:
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1]) if r.stdout.strip() else {}
+    return r, out, lines
+
+
+def _check_mock_stats(lines, P):
+    """One line per communicator: nobody timed out or saw a mismatch, and every rank ENQUEUED the same
+    number of collectives."""
+    assert len(lines) == P, lines
+    assert all(l["abort"] == 0 and l["err"] == 0 and l["host_abort"] == 0 for l in lines), lines
+    assert len({l["calls"] for l in lines}) == 1, f"ranks enqueued different numbers of collectives: {lines}"
+
+
+def _check_solution(out, P, n, mode):
+    assert out["ranks_identical"], out          # every rank holds the same x, iteration count and residual
+    assert out["converged"]
+    assert len(set(out["collectives_enqueued"])) == 1, out
+    assert abs(out["iters"] - out["iters_single"]) <= max(3, 0.02 * out["iters_single"]), out
+    assert out["true_residual"] <= 2 * (1e-9 if mode == "tridiag" else 1e-10) + 1e-13
+    assert out["x_vs_single"] < (1e-5 if mode == "tridiag" else 1e-8), out   # tridiag(1,2,1): cond ~ N^2/2
+    assert out["gemv_vs_single"] < 1e-13
+    base = n // P
+    assert out["partition"] == [[q * base, base + (n % P if q == P - 1 else 0)] for q in range(P)]
 
 
 @pytest.mark.parametrize("P,n,mode,overlap,exchange", [
@@ -43,55 +80,92 @@ def mock_lib():
     (8, 8192, "spd", 1, 1),
     (3, 1001, "tridiag", 1, 1),     # uneven split: falls back to exchange 0
 ])
-def test_rank_mode_multi_rank_on_mock_rccl(mock_lib, P, n, mode, overlap, exchange):
-    env = dict(os.environ, LD_PRELOAD=mock_lib)
-    r = subprocess.run([sys.executable, os.path.join(MOCK_DIR, "run_ranks.py"), str(P), str(n), mode, str(overlap),
-                        str(exchange)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["ranks_identical"], out          # every rank holds the same x, iteration count and residual
-    assert out["converged"]
-    assert abs(out["iters"] - out["iters_single"]) <= max(3, 0.02 * out["iters_single"]), out
-    assert out["true_residual"] <= 2 * (1e-9 if mode == "tridiag" else 1e-10) + 1e-13
-    assert out["x_vs_single"] < (1e-5 if mode == "tridiag" else 1e-8), out   # tridiag(1,2,1): cond ~ N^2/2
-    assert out["gemv_vs_single"] < 1e-13
-    base = n // P
-    assert out["partition"] == [[q * base, base + (n % P if q == P - 1 else 0)] for q in range(P)]
+def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, overlap, exchange):
+    r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--overlap", overlap, "--exchange", exchange)
+    _check_mock_stats(lines, P)
+    _check_solution(out, P, n, mode)
 
 
-MOCK_MP = os.path.join(MOCK_DIR, "libmock_rccl_mp.so")
+@pytest.mark.parametrize("P,n,mode,exchange,delay,chunk", [
+    # GPU outruns the host (small N: an iteration takes a few microseconds), run to convergence
+    (2, 1024, "tridiag", 0, "", 0),
+    (4, 2048, "tridiag", 0, "", 0),
+    (8, 4096, "spd", 0, "", 0),
+    (4, 2048, "tridiag", 1, "", 0),
+    (8, 4096, "spd", 1, "", 0),
+    # one rank's host lags far behind its GPU (it sleeps before every enqueue) while the others run ahead
+    (2, 1024, "tridiag", 0, "1:150", 0),
+    (4, 2048, "spd", 0, "2:200", 0),
+    (4, 2048, "spd", 1, "0:200", 0),
+    (8, 4096, "spd", 0, "3:100,6:250", 0),
+    # the host outruns the GPU (four 2 GB shards on one GPU: an iteration takes more than a millisecond)
+    (4, 32768, "spd", 0, "", 0),
+    (4, 32768, "spd", 1, "", 0),
+    # the solve split over several lam_hip_cg_iterate calls: the stop must also be agreed on across calls
+    (4, 2048, "tridiag", 0, "1:100", 7),
+    (2, 1024, "tridiag", 1, "", 5),
+])
+def test_stop_protocol_keeps_ranks_in_step(mock_async, tmp_path, P, n, mode, exchange, delay, chunk):
+    """Convergence under asynchronous collectives: all ranks must enqueue the same number of collectives
+    and the collective calls that follow the solve (solution gather, residual, GEMV) must still pair up."""
+    opts = ["--exchange", exchange]
+    if chunk:
+        opts += ["--chunk", chunk]
+    if n >= 32768:
+        opts += ["--cond", 50.0, "--no-single"]
+    r, out, lines = _run(mock_async, tmp_path, P, n, mode, *opts, env_extra={"MOCK_RCCL_HOST_DELAY_US": delay} if delay else None)
+    _check_mock_stats(lines, P)
+    assert out["converged"] and out["ranks_identical"], out
+    assert len(set(out["collectives_enqueued"])) == 1 and len(set(out["iterate_calls"])) == 1, out
+    assert out["true_residual"] <= 2 * (1e-9 if mode == "tridiag" else 1e-10) + 1e-13, out
+    if "iters_single" in out:
+        _check_solution(out, P, n, mode)
 
 
-@pytest.fixture(scope="module")
-def mock_mp_lib():
-    src = os.path.join(MOCK_DIR, "mock_rccl_mp.cpp")
-    if not os.path.exists(MOCK_MP) or os.path.getmtime(MOCK_MP) < os.path.getmtime(src):
-        # g++ and NOT linked against libamdhip64: the HIP symbols bind at first use to whatever runtime
-        # the process already holds (torch's, in the torchrun path) instead of dragging in a second one
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                        src, "-o", MOCK_MP, "-lrt", "-lpthread"], check=True)
-    return MOCK_MP
+def test_finalize_kernel_variant_matches_in_kernel_reduction(mock_async, tmp_path):
+    """option finalize=0 (separate 1-block reduction launches, the round-1 chain) and the default in-kernel
+    last-arriver reduction give bit-identical solves."""
+    outs = []
+    for fin in (1, 0):
+        r, out, lines = _run(mock_async, tmp_path, 4, 4096, "spd", "--finalize", fin)
+        _check_mock_stats(lines, 4)
+        os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
+        outs.append(out)
+    a, b = outs
+    assert a["iters"] == b["iters"] and a["rel_err"] == b["rel_err"] and a["true_residual"] == b["true_residual"]
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
-def test_bench_torchrun_path_end_to_end_on_mock_rccl(mock_mp_lib, nproc):
-    """The exact command line the driver uses for N > 1 GPUs -- torch.distributed.run, one process per
-    rank, gloo control plane, unique-id broadcast, both exchange modes, max-over-ranks timing, one JSON
-    line from rank 0 -- with every rank on GPU 0 and the multi-process mock in front of librccl."""
-    env = dict(os.environ, LD_PRELOAD=mock_mp_lib)
+def test_async_mock_catches_timing_dependent_stop(mock_async, tmp_path):
+    """Negative control: with LAM_HIP_DEBUG_LEVEL_STOP the host acts on ANY stop it has seen (the round-1
+    protocol).  A rank whose host lags its GPU then leaves the loop earlier than the others, the ranks'
+    collective sequences diverge -- and the stream-ordered mock reports it (a host-synchronous one cannot)."""
+    r, out, lines = _run(mock_async, tmp_path, 2, 1024, "tridiag", "--no-single", expect_ok=False,
+                         env_extra={"MOCK_RCCL_HOST_DELAY_US": "1:200", "LAM_HIP_DEBUG_LEVEL_STOP": "1",
+                                    "MOCK_RCCL_TIMEOUT_MS": "3000"})
+    diverged = r.returncode != 0 or len({l["calls"] for l in lines}) != 1 or any(l["abort"] for l in lines)
+    assert diverged, (out, lines)
+
+
+# ---- multi-process: the driver's exact torchrun command ------------------------------------------------
+def _bench_torchrun(mock, nproc, tmp_path, extra_env=None):
+    env = dict(os.environ, LD_PRELOAD=mock, GPU_MAX_HW_QUEUES="8", MOCK_RCCL_STATS_FILE=os.path.join(str(tmp_path), "st.jsonl"))
+    env.update(extra_env or {})
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     port = 29700 + nproc + os.getpid() % 100
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "20",
            "--warmup", "3", "--order", "8192"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+def _check_bench_line(r, nproc):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                          # exactly one JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == nproc and out["steps"] == 20 and out["scaling"] == "strong" and out["dtype"] == "f64"
     assert out["metric"] == "cg_iterations_per_sec" and out["value"] > 0
-    assert set(out["exchange_modes"]) == {"allreduce_x2+allgather_p", "allreduce_x2+allgather_p, no overlap", "allgather_Ap"}
+    assert set(out["exchange_modes"]) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap"}
     for m in out["exchange_modes"].values():
         assert m["value"] > 0
     # both exchanges solved the same problem: true residuals agree (different rounding only)
@@ -101,3 +175,26 @@ def test_bench_torchrun_path_end_to_end_on_mock_rccl(mock_mp_lib, nproc):
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
     assert abs(rf["algorithmic_bytes_per_launch"] - (8.0 * 8192 * 8192 / nproc + 8.0 * (8192 + 8192 / nproc))) < 1
+    assert out["host_plumbing"]["torch_imported"] is False     # the N>1 path is torch-free
+    return out
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_bench_torchrun_path_end_to_end_on_mock_rccl(mock_mp_lib, tmp_path, nproc):
+    """The exact command line the driver uses for N > 1 GPUs -- torch.distributed.run, one process per
+    rank, the package's own rendezvous (no torch in the workers), unique-id broadcast, both exchange modes,
+    max-over-ranks timing, one JSON line from rank 0 -- with every rank on GPU 0 and the multi-process
+    (host-synchronous) mock in front of librccl."""
+    _check_bench_line(_bench_torchrun(mock_mp_lib, nproc, tmp_path), nproc)
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_bench_torchrun_path_on_async_mock_across_processes(mock_async, tmp_path, nproc):
+    """Same command on the stream-ordered mock with the ranks in SEPARATE processes (slot ring shared
+    through HIP IPC): the process-per-GPU shape of the real deployment under asynchronous collectives."""
+    r = _bench_torchrun(mock_async, nproc, tmp_path)
+    if "HIP IPC is not available" in r.stderr or "hipIpcOpenMemHandle failed" in r.stderr:
+        pytest.skip("HIP IPC between processes is not available on this box")
+    _check_bench_line(r, nproc)
+    lines = [json.loads(l) for l in open(os.path.join(str(tmp_path), "st.jsonl"))]
+    _check_mock_stats(lines, nproc)
