@@ -90,25 +90,41 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
     bool load_matrix_from_file(const char *filename) override
     {
         if (!ensure_ctx()) return false;
+        // Whatever happens to THIS rank's part of the file, every rank reaches the agreement below: a rank
+        // whose block failed must not leave the others waiting in the solve's first collective.
+        const bool ok = agree(load_matrix_local(filename));
+        if (!ok && is_root()) fprintf(stderr, "Failed to read matrix rows\n");
+        return ok;
+    }
+
+    bool load_rhs_from_file(const char *filename) override
+    {
+        if (!ensure_ctx()) return false;
+        return agree(load_rhs_local(filename));
+    }
+
+  private:
+    bool load_matrix_local(const char *filename)
+    {
         int fd = open(filename, O_RDONLY);
         if (fd < 0) {
-            if (is_root()) fprintf(stderr, "Cannot open output file\n");   // the reference's wording
+            file_error("Cannot open output file\n");   // the reference's wording
             return false;
         }
         uint64_t hdr[2], rows = 0, cols = 0;
         struct stat sb;
         if (pread(fd, hdr, sizeof hdr, 0) != (ssize_t)sizeof hdr || fstat(fd, &sb) != 0) {
-            if (is_root()) fprintf(stderr, "Cannot read matrix header\n");
+            file_error("Cannot read matrix header\n");
             close(fd);
             return false;
         }
         if (!parse_bin_header(hdr, (uint64_t)sb.st_size, sizeof(FloatingType), &rows, &cols)) {
-            if (is_root()) fprintf(stderr, "Matrix file is shorter than its header says\n");
+            file_error("Matrix file is shorter than its header says\n");
             close(fd);
             return false;
         }
         if (rows != cols) {
-            if (is_root()) fprintf(stderr, "Matrix has to be square\n");
+            file_error("Matrix has to be square\n");
             close(fd);
             return false;
         }
@@ -124,7 +140,7 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         const uint64_t file_bytes = 16 + rows * cols * sizeof(FloatingType);
         void *map = mmap(nullptr, file_bytes, PROT_READ, MAP_PRIVATE, fd, 0);
         if (map == MAP_FAILED) {
-            if (is_root()) fprintf(stderr, "Cannot map matrix file\n");
+            file_error("Cannot map matrix file\n");
             close(fd);
             return false;
         }
@@ -143,35 +159,31 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         }
         munmap(map, file_bytes);
         close(fd);
-        // a rank whose block failed must not leave the others waiting in the solve's first collective
-        ok = agree(ok);
-        if (!ok && is_root()) fprintf(stderr, "Failed to read matrix rows\n");
         return ok;
     }
 
-    bool load_rhs_from_file(const char *filename) override
+    bool load_rhs_local(const char *filename)
     {
-        if (!ensure_ctx()) return false;
         FILE *file = fopen(filename, "rb");
         if (file == nullptr) {
-            if (is_root()) fprintf(stderr, "Cannot open output file\n");
+            file_error("Cannot open output file\n");
             return false;
         }
         uint64_t hdr[2] = {0, 0}, rows = 0, cols = 0;
         struct stat sb;
         if (fread(hdr, sizeof(uint64_t), 2, file) != 2 || fstat(fileno(file), &sb) != 0) { fclose(file); return false; }
         if (!parse_bin_header(hdr, (uint64_t)sb.st_size, sizeof(FloatingType), &rows, &cols)) {
-            if (is_root()) fprintf(stderr, "Right hand side file is shorter than its header says\n");
+            file_error("Right hand side file is shorter than its header says\n");
             fclose(file);
             return false;
         }
         if (cols != 1) {
-            if (is_root()) fprintf(stderr, "Right hand side has to have just a single column\n");
+            file_error("Right hand side has to have just a single column\n");
             fclose(file);
             return false;
         }
         if (rows != _num_cols) {
-            if (is_root()) fprintf(stderr, "Size of right hand side does not match the matrix\n");
+            file_error("Size of right hand side does not match the matrix\n");
             fclose(file);
             return false;
         }
@@ -179,8 +191,10 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         bool ok = fread(b.data(), sizeof(FloatingType), rows, file) == rows;
         fclose(file);
         if (ok && lam_hip_set_rhs(_ctx, b.data()) != 0) { report("set_rhs"); ok = false; }
-        return agree(ok);
+        return ok;
     }
+
+  public:
 
     bool save_result_to_file(const char *filename) const override
     {
@@ -268,6 +282,12 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         return true;
     }
     bool is_root() const { return _rank == 0; }
+    // a file problem may exist on one rank only (its own row block): say it wherever it happens
+    void file_error(const char *msg) const
+    {
+        if (is_root()) fputs(msg, stderr);
+        else fprintf(stderr, "rank %d: %s", _rank, msg);
+    }
     // true iff the step succeeded on EVERY rank (collective in the one-process-per-GPU class)
     bool agree(bool ok) const
     {

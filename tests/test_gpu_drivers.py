@@ -207,7 +207,12 @@ def test_env_launched_driver_multi_rank(tmp_path, mock_mp_lib, golden, oracle, e
         procs.append(subprocess.Popen([os.path.join(TEST_DIR, exe_name), "-A", os.path.join(GOLDEN, g["name"] + ".matrix.bin"),
                                        "-b", os.path.join(GOLDEN, g["name"] + ".rhs.bin"), "-o", str(sol), "-e", repr(g["tol"])],
                                       env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=300) for p in procs]
+    try:
+        outs = [p.communicate(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     assert all(p.returncode == 0 for p in procs), outs
     f = _csv(outs[0][0])
     assert int(f[0]) == g["n"] and f[1] == str(P)
@@ -235,7 +240,12 @@ def test_rank_local_load_failure_fails_on_every_rank(tmp_path, mock_mp_lib, gold
         procs.append(subprocess.Popen([RCCL_EXE, "-A", str(bad) if rank == 1 else good, "-b",
                                        os.path.join(GOLDEN, g["name"] + ".rhs.bin"), "-o", str(tmp_path / "s.bin")],
                                       env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=120) for p in procs]
+    try:
+        outs = [p.communicate(timeout=60) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     assert [p.returncode for p in procs] == [1, 1], outs
 
 
