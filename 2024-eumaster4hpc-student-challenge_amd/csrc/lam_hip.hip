@@ -6,7 +6,7 @@
 // per shard and iteration k:
 //   gemv_coop_kernel -> [exchange p.Ap partials] -> update_xr_kernel -> [exchange r.r partials]
 //   -> update_p_kernel (stores the new p slice into every replica of p) -> [all-gather p]
-// With several shards the last workgroup of the producer kernel leaves the shard's partial as one
+// With several shards a reducer workgroup inside the producer launch leaves the shard's partial as one
 // double (lam_kernels.h, Finalize), so an iteration is 3 launches for every shard count.  "Exchange"
 // is (a) nothing for one shard, (b) direct peer stores + cross-stream events when one process drives
 // several shards (xGMI point-to-point), (c) RCCL when there is one process per GPU: an 8-byte-per-
@@ -68,7 +68,8 @@ struct ShardBase {
     double *part_vec = nullptr;  // [vec_blocks]
     double *gather_a = nullptr;  // [kMaxShards] p.Ap partials of all shards (or the reduced scalar at [0])
     double *gather_b = nullptr;  // [kMaxShards] r.r partials
-    unsigned *tickets = nullptr; // [2] arrival counters of the in-kernel reductions (GEMV, update_xr)
+    double *part_aux = nullptr;  // [kVecBlocksMax] partials of the checks outside the iteration (true residual)
+    int part_gemv_cap = 0;       // entries allocated behind part_gemv
     CgScalars *sc = nullptr;     // device scalars
     CgScalars *sc_host = nullptr;// pinned mirror (filled by an async copy at the end of a call)
     int *host_flags = nullptr;   // pinned, device-visible: [0] last finished iteration, [1] stop
@@ -323,7 +324,7 @@ struct Impl {
         GemvArgs<TA, TV> a;
         a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
         if (fin != nullptr && partial != nullptr) a.fin = *fin;
-        else { a.fin.ticket = nullptr; a.fin.dst.n = 0; a.fin.slot = 0; }
+        else { a.fin.active = 0; a.fin.dst.n = 0; a.fin.slot = 0; }
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
         a.seg_begin[0] = 0; a.seg_end[0] = c->n; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
         if (panel == 1) { a.seg_begin[0] = lo; a.seg_end[0] = hi; }
@@ -335,7 +336,7 @@ struct Impl {
             if (a.nseg == 0) return 0;
             if (a.nseg == 1) { a.seg_begin[1] = a.seg_end[1] = 0; }
         }
-        const int grid = kernel_grid(c, s.nrows);
+        const int grid = kernel_grid(c, s.nrows) + (a.fin.active ? 1 : 0);     // + the reducer workgroup (Finalize)
         if (fast_ok(c)) {
             switch (variant(c)) {
             default:
@@ -435,7 +436,7 @@ void free_shard(ShardBase &s, bool keep_matrix = false)
     const size_t keepCap = keep_matrix ? s.A_capacity : 0;
     if (keep_matrix) s.A = nullptr;
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
-                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.tickets};
+                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.part_aux};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = nullptr;
     s.symv_tasks = nullptr;
@@ -447,7 +448,7 @@ void free_shard(ShardBase &s, bool keep_matrix = false)
     s.A = keepA;
     s.A_capacity = keepCap;
     s.part_gemv = s.part_vec = s.gather_a = s.gather_b = nullptr;
-    s.tickets = nullptr;
+    s.part_aux = nullptr;
     s.sc = nullptr; s.sc_host = nullptr;
 }
 
@@ -536,7 +537,7 @@ int sync_all(lam_hip_ctx *c)
 Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
 {
     Finalize f;
-    f.ticket = nullptr;
+    f.active = 0;
     f.dst.n = 0;
     f.slot = s.index;
     if (!c->rank_mode && c->total_shards == 1) return f;
@@ -545,7 +546,7 @@ Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
         f.dst.n = (int)c->sh.size();
         for (int j = 0; j < f.dst.n; j++) f.dst.p[j] = second ? (void *)c->sh[j].gather_b : (void *)c->sh[j].gather_a;
     }
-    if (c->opt_finalize) f.ticket = s.tickets + (second ? 1 : 0);
+    f.active = c->opt_finalize ? 1 : 0;
     return f;
 }
 
@@ -667,6 +668,23 @@ namespace {
 template <typename T> struct ImplTraits;
 template <typename TA_, typename TV_> struct ImplTraits<Impl<TA_, TV_>> { using TA = TA_; using TV = TV_; };
 
+// Fill the partial arrays with the sentinel the reducer workgroups wait on (lam_kernels.h, Finalize).
+// Enqueued at the end of cg_init: whatever wrote plain values into them before (cg_init's own partials,
+// a roofline probe) is behind it in stream order.
+int arm_partials(lam_hip_ctx *c)
+{
+    if ((!c->rank_mode && c->total_shards == 1) || !c->opt_finalize) return 0;
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        hipLaunchKernelGGL(arm_partials_kernel, dim3(std::max(1, std::min(64, s.part_gemv_cap / kBlock))), dim3(kBlock), 0, s.stream,
+                           s.part_gemv, s.part_gemv_cap);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(arm_partials_kernel, dim3(1), dim3(kBlock), 0, s.stream, s.part_vec, kVecBlocksMax);
+        HIPCHK(c, hipGetLastError());
+    }
+    return 0;
+}
+
 // gather-Ap exchange: CG state = x slice, FULL r and p on every rank
 int do_cg_init_exchange1(lam_hip_ctx *c)
 {
@@ -683,6 +701,7 @@ int do_cg_init_exchange1(lam_hip_ctx *c)
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc);
         HIPCHK(c, hipGetLastError());
+        LAMCHK(arm_partials(c));
         c->k_done = 0;
         c->cg_ready = true;
         c->cg_exchange1 = true;
@@ -702,7 +721,7 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         // 1. GEMV straight into this rank's record; its last workgroup leaves the rank's p.Ap partial
         //    behind the slice (with option "finalize" = 0: a 1-block launch does)
         Finalize f;
-        f.ticket = c->opt_finalize ? s.tickets : nullptr;
+        f.active = c->opt_finalize ? 1 : 0;
         f.dst.n = 1; f.dst.p[0] = rec + base * sizeof(TV); f.slot = 0;
         HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
         LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc, 0, 0, 0, &f));
@@ -750,6 +769,7 @@ int do_cg_init(lam_hip_ctx *c)
             HIPCHK(c, hipGetLastError());
         }
         LAMCHK(gather_p_step(c));
+        LAMCHK(arm_partials(c));
         c->k_done = 0;
         c->cg_ready = true;
         return 0;
@@ -801,9 +821,9 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             LAMCHK(set_dev(c, s));
             const double *red; int nred;
             red_source(c, s, false, true, &red, &nred);
-            hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
-                               (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec,
-                               make_finalize(c, s, true));
+            const Finalize fb = make_finalize(c, s, true);
+            hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + (fb.active ? 1 : 0)), dim3(kBlock), 0, s.stream, red, nred,
+                               s.sc, k, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb);
             HIPCHK(c, hipGetLastError());
         }
         LAMCHK(reduce_step(c, true, false, true, fin));
@@ -968,11 +988,11 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         const int gemv_blocks_max = (int)s.nrows + 1;
         s.vec_blocks = vec_grid(s.nrows);
         HIPCHK(c, hipMalloc((void **)&s.part_gemv, sizeof(double) * (size_t)gemv_blocks_max));
+        s.part_gemv_cap = gemv_blocks_max;
         HIPCHK(c, hipMalloc((void **)&s.part_vec, sizeof(double) * kVecBlocksMax));
+        HIPCHK(c, hipMalloc((void **)&s.part_aux, sizeof(double) * kVecBlocksMax));
         HIPCHK(c, hipMalloc((void **)&s.gather_a, sizeof(double) * kMaxShards));
         HIPCHK(c, hipMalloc((void **)&s.gather_b, sizeof(double) * kMaxShards));
-        HIPCHK(c, hipMalloc((void **)&s.tickets, 64));
-        HIPCHK(c, hipMemsetAsync(s.tickets, 0, 64, s.stream));
         if (c->rank_mode) {
             HIPCHK(c, hipMalloc(&s.r_full, n * ev + 16));
             HIPCHK(c, hipMalloc(&s.ap_gather, (size_t)c->nranks * ((n / (uint64_t)c->nranks + 1) * ev + 8) + 16));
@@ -1452,14 +1472,15 @@ int lam_hip_true_residual(lam_hip_ctx *c, double *rel_res)
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             std::vector<double> h(2 * kVecBlocksMax);
-            hipLaunchKernelGGL((resid_partial_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b, (const TV *)s.Ap, s.nrows, s.part_vec);
+            // part_aux, not part_vec: the iteration's partial arrays hold the reducer's sentinels between iterations
+            hipLaunchKernelGGL((resid_partial_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b, (const TV *)s.Ap, s.nrows, s.part_aux);
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(h.data(), s.part_vec, sizeof(double) * s.vec_blocks, hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(c, hipMemcpyAsync(h.data(), s.part_aux, sizeof(double) * s.vec_blocks, hipMemcpyDeviceToHost, s.stream));
             HIPCHK(c, hipStreamSynchronize(s.stream));
             for (int i = 0; i < s.vec_blocks; i++) num += h[i];
-            hipLaunchKernelGGL((dot_partial_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b, (const TV *)s.b, s.nrows, s.part_vec);
+            hipLaunchKernelGGL((dot_partial_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const TV *)s.b, (const TV *)s.b, s.nrows, s.part_aux);
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(h.data(), s.part_vec, sizeof(double) * s.vec_blocks, hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(c, hipMemcpyAsync(h.data(), s.part_aux, sizeof(double) * s.vec_blocks, hipMemcpyDeviceToHost, s.stream));
             HIPCHK(c, hipStreamSynchronize(s.stream));
             for (int i = 0; i < s.vec_blocks; i++) den += h[i];
         }
@@ -1617,7 +1638,7 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
     else if (!strcmp(name, "overlap")) c->opt_overlap = value;
     else if (!strcmp(name, "exchange")) { c->opt_exchange = value; c->cg_ready = false; }
-    else if (!strcmp(name, "finalize")) c->opt_finalize = value;
+    else if (!strcmp(name, "finalize")) { c->opt_finalize = value; c->cg_ready = false; }
     else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
     else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
     else if (!strcmp(name, "symmetric")) c->opt_symmetric = value;

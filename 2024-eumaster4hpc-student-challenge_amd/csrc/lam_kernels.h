@@ -31,6 +31,8 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace lam {
 
 constexpr int kBlock = 256;          // 4 waves of 64
@@ -94,61 +96,96 @@ struct PtrList {                      // destinations of a replicated store (one
     int n;
 };
 
-// In-kernel reduction of the per-workgroup partials by the LAST workgroup to finish (more than one
-// shard only).  With one shard the consumer kernel sums the partials itself; with several, the shard's
-// partial has to exist as ONE number before the exchange, and a separate 1-block launch for that costs
-// a kernel boundary plus a launch on the iteration's critical path.  Protocol (cdna_hip_programming.md
-// section 5, split-K ticket in its write-through form): thread 0 of every workgroup stores its partial
-// with an agent-scope (sc1, write-through) store, drains it, then draws a ticket with a relaxed
-// agent-scope fetch_add; the workgroup that draws gridDim.x-1 reads ALL partials with agent-scope (sc1)
-// loads in the fixed order of block_sum_array -- the result is bit-identical to a separate reduction
-// launch -- stores it to slot `slot` of every destination and re-arms the ticket for the next launch.
+// In-kernel reduction of the per-workgroup partials (more than one shard only).  With one shard the
+// consumer kernel sums the partials itself; with several, the shard's partial has to exist as ONE number
+// before the exchange, and a separate 1-workgroup launch for that costs a launch + a kernel boundary on
+// the iteration's critical path (measured 6.5 us each, profiles/r02_rank_mode_chain.csv).  Instead the
+// producer launch carries ONE EXTRA workgroup, the reducer (block gridDim.x-1):
+//   * every compute workgroup stores its partial with a single 8-byte agent-scope (sc1, write-through)
+//     store and is done -- no fence, no counter, no wait: the value is its own "ready" flag, because the
+//     slot held a sentinel (a NaN bit pattern no computation produces) until then;
+//   * the reducer polls the slots with sc1 loads in the fixed order of block_sum_array -- so the sum is
+//     bit-identical to a separate reduction launch --, writes the total to slot `slot` of every
+//     destination and re-arms the slots with the sentinel for the next launch.
+// The reducer is dispatched after the compute workgroups and only ever waits for workgroups that are
+// already running; its spin is bounded (kFinalizeTimeoutTicks) and ends in a NaN total, never in a hang.
+// (An arrival counter drawn by every workgroup -- store, drain, fetch_add -- was measured first: the
+// two memory round trips at the end of each of 11584 GEMV workgroups cost 45 us per launch, four times
+// what the removed launch had cost.)
 struct Finalize {
-    unsigned *ticket;                 // null: no in-kernel reduction
+    int active;                       // 0: no in-kernel reduction (the launch has no reducer workgroup)
     PtrList dst;
     int slot;
 };
+constexpr unsigned long long kPartialSentinel = 0x7ff8dead5eedbeefull;   // quiet NaN with a payload nothing computes
+constexpr unsigned long long kFinalizeTimeoutTicks = 5ull * 100000000ull; // wall_clock64() runs at 100 MHz: 5 s
 
-// block_sum_array over partials other workgroups of THIS launch stored write-through: every load is an
-// agent-scope (sc1) load, same order as block_sum_array.
-__device__ __forceinline__ double block_sum_array_sc1(const double *src, int n, double *s_red)
+__device__ __forceinline__ bool is_reducer_block(const Finalize &f) { return f.active && blockIdx.x == gridDim.x - 1; }
+__device__ __forceinline__ unsigned compute_blocks(const Finalize &f) { return gridDim.x - (f.active ? 1u : 0u); }
+
+// compute workgroups: thread 0 stores the workgroup's partial (see Finalize)
+__device__ __forceinline__ void publish_partial(double t, double *partial, const Finalize &f)
 {
-    double v = 0.0;
-    int i = threadIdx.x < kBlock ? (int)threadIdx.x : n;      // wider workgroups: the extra waves add 0
-    auto ld = [&](int j) { return __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-#pragma unroll 2
-    for (; i + 7 * kBlock < n; i += 8 * kBlock) {
-        const double a0 = ld(i), a1 = ld(i + kBlock), a2 = ld(i + 2 * kBlock), a3 = ld(i + 3 * kBlock);
-        const double a4 = ld(i + 4 * kBlock), a5 = ld(i + 5 * kBlock), a6 = ld(i + 6 * kBlock), a7 = ld(i + 7 * kBlock);
-        v += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    }
-    for (; i < n; i += kBlock) v += ld(i);
-    return block_sum(v, s_red);
+    if (threadIdx.x != 0) return;
+    if (f.active) __hip_atomic_store(partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partial[blockIdx.x] = t;
 }
 
-// Store this workgroup's partial `t` (valid in thread 0) and, if `f.ticket` is set, let the last
-// workgroup of the launch reduce all of them (see Finalize).  Called by EVERY thread of the workgroup
-// (kBlock threads or more), outside divergent code.
-__device__ __forceinline__ void publish_partial(double t, double *partial, const Finalize &f, double *s_red /*[kWaves]*/)
+// the reducer workgroup (every thread of it; workgroups wider than kBlock: the extra waves idle)
+__device__ __forceinline__ void reduce_partials(double *partial, const Finalize &f, double *s_red /*[kWaves]*/)
 {
-    if (f.ticket == nullptr) {
-        if (threadIdx.x == 0) partial[blockIdx.x] = t;
-        return;
+    const int n = (int)gridDim.x - 1;
+    const unsigned long long t0 = wall_clock64();
+    bool timed_out = false;
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(partial);
+    auto ld = [&](int j) { return __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // CNT slots (stride kBlock): all loads of a polling round are in flight together, so the reducer is at
+    // most a round trip or two behind the last producer; then the slots are re-armed
+    auto take = [&](int base, auto cnt_tag, double *out) {
+        constexpr int CNT = decltype(cnt_tag)::value;
+        unsigned long long b[CNT];
+#pragma unroll
+        for (int k = 0; k < CNT; k++) b[k] = ld(base + k * kBlock);
+        bool pending = true;
+        while (pending && !timed_out) {
+            pending = false;
+#pragma unroll
+            for (int k = 0; k < CNT; k++)
+                if (b[k] == kPartialSentinel) { b[k] = ld(base + k * kBlock); pending |= b[k] == kPartialSentinel; }
+            if (pending) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > kFinalizeTimeoutTicks) timed_out = true;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CNT; k++) {
+            __hip_atomic_store(slots + base + k * kBlock, kPartialSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[k] = __longlong_as_double((long long)b[k]);
+        }
+    };
+    double v = 0.0;
+    int i = threadIdx.x < kBlock ? (int)threadIdx.x : n;
+    for (; i + 7 * kBlock < n; i += 8 * kBlock) {      // same grouping and order as block_sum_array
+        double a[8];
+        take(i, std::integral_constant<int, 8>(), a);
+        v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == gridDim.x - 1 ? 1 : 0;
+    for (; i < n; i += kBlock) {
+        double a[1];
+        take(i, std::integral_constant<int, 1>(), a);
+        v += a[0];
     }
-    __syncthreads();
-    if (!s_last) return;
-    const double total = block_sum_array_sc1(partial, (int)gridDim.x, s_red);
-    if (threadIdx.x == 0) {
+    const double total = block_sum(v, s_red);
+    if (threadIdx.x == 0)
         for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
-        __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+}
+
+// arm the slots (cg_init, and whenever a launch without a reducer may have written plain values)
+__global__ void __launch_bounds__(kBlock)
+arm_partials_kernel(double *partial, int n)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        reinterpret_cast<unsigned long long *>(partial)[i] = kPartialSentinel;
 }
 
 template <typename TA> struct MatVec;  // 16-byte vector of matrix elements
@@ -232,6 +269,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -326,7 +364,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
             for (int w = 1; w < kWaves; w++) t += s_red[w];
         }
-        publish_partial(t, a.partial, a.fin, s_red);
+        publish_partial(t, a.partial, a.fin);
     }
 }
 
@@ -352,6 +390,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -447,7 +486,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
             for (int r = 1; r < R; r++) t += s_dot[r];
         }
-        publish_partial(t, a.partial, a.fin, s_red);
+        publish_partial(t, a.partial, a.fin);
     }
 }
 
@@ -480,6 +519,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -591,7 +631,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
 #pragma unroll
             for (int w = 1; w < kWaves; w++) t += s_red[w];
         }
-        publish_partial(t, a.partial, a.fin, s_red);
+        publish_partial(t, a.partial, a.fin);
     }
 }
 
@@ -763,6 +803,7 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
 {
     __shared__ double s_red[kWaves];
     if (a.sc != nullptr && a.sc->stop) return;
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint64_t row = (uint64_t)blockIdx.x * kWaves + wave;
@@ -819,7 +860,7 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
             for (int w = 1; w < kWaves; w++) t += s_red[w];
         }
-        publish_partial(t, a.partial, a.fin, s_red);
+        publish_partial(t, a.partial, a.fin);
     }
 }
 
@@ -885,12 +926,14 @@ update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
+    if (is_reducer_block(fin)) { reduce_partials(partial, fin, s_red); return; }
     const double pAp = block_sum_array(red, nred, s_red);
     const double rr = sc->rr[(k + 1) & 1];
     const double alpha_d = rr / pAp;
     const TV alpha = (TV)alpha_d;
     double acc = 0.0;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t stride = (uint64_t)compute_blocks(fin) * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
         x[i] = alpha * p_loc[i] + x[i];
         const TV ri = -alpha * Ap[i] + r[i];
         r[i] = ri;
@@ -898,7 +941,7 @@ update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
     }
     double t = block_sum(acc, s_red);
     if (threadIdx.x == 0 && blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
-    publish_partial(t, partial, fin, s_red);
+    publish_partial(t, partial, fin);
 }
 
 // rr' = r.r ; beta = rr'/rr ; if sqrt(rr'/bb) < tol: stop (p untouched) else p_slice = r + beta p

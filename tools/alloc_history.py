@@ -66,6 +66,23 @@ def main():
     d.generate_random_spd(n, 1, 1e4); d.generate_random_rhs(2); d.cg_init()
     r5 = measure(d, "S5 one context 65536 -> 32768, free + hipMalloc", n)
     d.close()
+    # S6: how long does the slow period after a large free last?  One context (32768), a 34 GB neighbour is
+    # created and destroyed, then the GEMV is sampled every ~60 ms.
+    e = lam.Solver(lam.F64)
+    e.generate_random_spd(n, 1, 1e4); e.generate_random_rhs(2); e.cg_init()
+    base = sorted(e.gemv_only(20) for _ in range(5))[2]
+    f = lam.Solver(lam.F64)
+    f.generate_random_spd(big, 3, 1e4)
+    f.close()
+    t0 = time.perf_counter()
+    series = []
+    while time.perf_counter() - t0 < 4.0:
+        t = time.perf_counter() - t0
+        series.append((t, e.gemv_only(20)))
+        time.sleep(0.03)
+    print(f"S6 GEMV N={n} before the free: {base*1e3:.4f} ms; after hipFree of 34 GB (t = seconds since the free returned):")
+    print("   " + "  ".join(f"{t:.2f}s:{v/base:.3f}" for t, v in series[::2]))
+    e.close()
     print("relative to S0 (gemv, symv): " + "  ".join(f"{k} {v[0]/r0[0]:.3f}/{v[1]/r0[1]:.3f}" for k, v in
           (("S0'", r0b), ("S1", r1), ("S2", r2), ("S3", r3), ("S2'", r2b), ("S4", r4), ("S5", r5))))
 
