@@ -13,7 +13,7 @@ series is one problem.  The matrix is the device-generated random dense SPD syst
 (lam_hip_generate_random_spd, cond=1e6 so CG is still iterating at the end of the run).
 At N=1 GPU the line also carries, under "also", configs[1] (N=32768) and the sizes the reference
 published numbers for (N=10000/20000/40000, TESTS/BEST_RESULTS:362-372) with the per-iteration cost
-outside the GEMV ("other_us").
+outside the GEMV ("other_us"); they run after the headline in the same process and context.
 
 Under a launcher (RANK/WORLD_SIZE in the environment) every rank is one process on one GPU; the ranks
 find each other through the package's own socket rendezvous (no torch in the process: torch bundles a
@@ -92,14 +92,16 @@ def cpu_baseline(sample_n, iters):
             "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
 
 
-def run_config(make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False):
-    s = make_solver()
-    s.generate_random_spd(n, seed, cond)
-    s.generate_random_rhs(seed + 1)
-    if symmetric:
-        s.set_option("symmetric", 1)
-        if s.get_option("symmetric_effective") != 1:
-            raise SystemExit("option 'symmetric' is not available for this configuration")
+def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False, generate=True):
+    """W untimed + K timed CG iterations on solver `s`.  The context keeps its matrix allocation when N
+    shrinks (grow-only), so several configurations can follow each other in one process without a large
+    hipFree in between ("allocation history")."""
+    if generate:
+        s.generate_random_spd(n, seed, cond)
+        s.generate_random_rhs(seed + 1)
+    s.set_option("symmetric", 1 if symmetric else 0)
+    if symmetric and s.get_option("symmetric_effective") != 1:
+        raise RuntimeError("option 'symmetric' is not available for this configuration")
     s.cg_init()
     if warmup > 0:
         s.cg_iterate(warmup, 0.0)
@@ -108,15 +110,7 @@ def run_config(make_solver, n, warmup, steps, barrier, seed=1234, cond=1e6, symm
     st = s.cg_iterate(steps, 0.0)          # returns after its streams are synchronised
     barrier()
     dt = time.perf_counter() - t0
-    return s, st, dt
-
-
-def side_run(args, n, symmetric=False):
-    """One extra configuration in a process of its own (before this process touches the GPU)."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--order", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--no-also", "--no-cpu-baseline"] + (["--symmetric"] if symmetric else [])
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    return st, dt
 
 
 def traffic_record(n, n_gpus):
@@ -159,41 +153,12 @@ def main():
     profiled = under_profiler()
     solo = rank == 0 and not use_dist and max(1, args.gpus) == 1
 
-    # Child processes go FIRST: nothing has touched the GPU yet (a process that has initialised the GPU
-    # must not fork+exec on this pool), and never under a profiler (its tool library initialises the GPU
-    # before main()).
+    # The one child process (the CPU baseline) goes FIRST: nothing has touched the GPU yet (a process that
+    # has initialised the GPU must not fork+exec on this pool), and never under a profiler (its tool
+    # library initialises the GPU before main()).
     cb = None
     if solo and not args.no_cpu_baseline and not profiled:
         cb = cpu_baseline(args.cpu_sample_n, args.cpu_sample_iters)
-
-    # Other sizes: configs[1] (N=32768) and the reference's published sizes, one process each (a fresh
-    # address space per configuration, DESIGN.md section 6 "allocation history").
-    also = None
-    if solo and not args.no_also and not profiled and not args.symmetric:
-        also = []
-        for n_also in ALSO_SIZES:
-            if n_also == args.n:
-                continue
-            try:
-                d = side_run(args, n_also)
-                also.append({"n": n_also, "value": d["value"], "ms_per_step": d["ms_per_step"], "gemv_ms": d["gemv_ms"],
-                             "other_us": (d["ms_per_step"] - d["gemv_ms"]) * 1e3, "gemv_gbps": d["gemv_gbps_per_gpu"],
-                             "roofline_frac": d["roofline"]["frac"], "kernel": d["roofline"]["kernel"]})
-            except Exception as e:   # noqa: BLE001
-                sys.stderr.write(f"[bench] side run N={n_also} failed: {e}\n")
-
-    # Opt-in "symmetric" product (reads only the upper triangle; 1 GPU), reported beside the headline,
-    # never as it.
-    sym = None
-    if solo and not args.no_also and not profiled and not args.symmetric:
-        try:
-            d = side_run(args, args.n, symmetric=True)
-            sym = {"what": "lam_hip_set_option('symmetric', 1): the product reads only the upper triangle of the SPD matrix "
-                           "(two-pass, deterministic); same problem, own process; NOT the headline (different algorithm, "
-                           "single GPU only)", "value": d["value"], "ms_per_step": d["ms_per_step"],
-                   "product_ms": d["gemv_ms"], "rel_residual_true": d["rel_residual_true"]}
-        except Exception as e:   # noqa: BLE001
-            sys.stderr.write(f"[bench] symmetric-option side run failed: {e}\n")
 
     if use_dist:
         uid = rdzv.broadcast(lam.get_unique_id() if rank == 0 else b"")
@@ -218,7 +183,8 @@ def main():
         parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores"
 
     n = args.n
-    s, st, dt = run_config(make_solver, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
+    s = make_solver()
+    st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
     kernel_name = s.gemv_kernel_name()
 
     def max_over_ranks(dt_, st_):
@@ -263,6 +229,31 @@ def main():
                     (base + "ONE RCCL all-gather of [Ap slice | p.Ap partial] per iteration (full-length r, p per rank)",))
         dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])
     n_coll = s.get_option("collectives_enqueued")
+
+    # Side measurements, same process, same context, AFTER the headline (N=1 only, not under a profiler):
+    # the opt-in symmetric product on the same system, then configs[1] (N=32768) and the sizes the reference
+    # published numbers for (TESTS/BEST_RESULTS:362-372), largest first so the matrix allocation is re-used.
+    also, sym = None, None
+    if solo and not args.no_also and not profiled and not args.symmetric:
+        try:
+            st_s, dt_s = run_config(s, n, args.warmup, args.steps, barrier, symmetric=True, generate=False)
+            sym = {"what": "lam_hip_set_option('symmetric', 1): the product reads only the upper triangle of the SPD matrix "
+                           "(two-pass, deterministic); same system, same context; NOT the headline (different algorithm, "
+                           "single GPU only)", "value": args.steps / dt_s, "ms_per_step": dt_s / args.steps * 1e3,
+                   "product_ms": st_s["t_gemv"] * 1e3, "rel_residual_true": s.true_residual()}
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write(f"[bench] symmetric-option side run failed: {e}\n")
+        also = []
+        for n_also in sorted((x for x in ALSO_SIZES if x != n), reverse=True):
+            try:
+                st_a, dt_a = run_config(s, n_also, args.warmup, args.steps, barrier)
+                ms = dt_a / args.steps * 1e3
+                gbps = st_a["gemv_bytes"] / st_a["t_gemv"] / 1e9
+                also.append({"n": n_also, "value": args.steps / dt_a, "ms_per_step": ms, "gemv_ms": st_a["t_gemv"] * 1e3,
+                             "other_us": (ms - st_a["t_gemv"] * 1e3) * 1e3, "gemv_gbps": gbps, "roofline_frac": gbps / HBM_PEAK_GBPS,
+                             "kernel": s.gemv_kernel_name()})
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write(f"[bench] side run N={n_also} failed: {e}\n")
     s.close()
 
     ms_per_step = dt / args.steps * 1e3

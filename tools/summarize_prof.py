@@ -8,7 +8,7 @@ profiles/<tag>_gemv_by_grid.csv (GEMV launches grouped by grid size, from the ke
 PMC directories are given, profiles/<tag>_hbm_counters.csv plus an entry in profiles/traffic.json.
 HBM bytes follow MI355X_MICROARCH.md "HBM": bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950
 FETCH_SIZE reports exactly half of the bytes of a 16 B/lane coalesced streaming read."""
-import argparse, collections, csv, glob, json, os, shutil, sys
+import argparse, collections, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("tag"); ap.add_argument("stats_dir")
     ap.add_argument("fetch_dir", nargs="?"); ap.add_argument("write_dir", nargs="?")
     ap.add_argument("--n", type=int, default=65536); ap.add_argument("--p", type=int, default=1)
-    ap.add_argument("--kernel", default="gemv_tile_kernel")
+    ap.add_argument("--kernel", default="gemv_coop_kernel")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles"); os.makedirs(out, exist_ok=True)
     shutil.copy(one(os.path.join(a.stats_dir, "**", "*_kernel_stats.csv")), os.path.join(out, f"{a.tag}_kernel_stats.csv"))
@@ -51,7 +51,14 @@ def main():
         write = sum(ctr[(grid, "WRITE_SIZE")]) / len(ctr[(grid, "WRITE_SIZE")])
         tpath = os.path.join(out, "traffic.json")
         tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        try:
+            commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = None
+        full_name = next((r["Kernel_Name"] for r in csv.DictReader(open(one(os.path.join(a.fetch_dir, "**", "*_counter_collection.csv"))))
+                          if a.kernel in r["Kernel_Name"] and r["Grid_Size"] == grid), a.kernel)
         tj[f"n{a.n}_p{a.p}"] = {"hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "FETCH_SIZE_KiB": fetch,
+                               "commit": commit, "kernel": full_name,
                                "WRITE_SIZE_KiB": write, "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
                                "source": f"profiles/{a.tag}_hbm_counters.csv", "grid_threads": int(grid)}
         json.dump(tj, open(tpath, "w"), indent=1)
