@@ -138,12 +138,20 @@ def partition(n, num_shards, shard):
 
 
 def _read_bin(path, dtype):
+    """(rows, cols) of a matrix / vector file.  Same rule as LAM::parse_bin_header (the C++ loaders): the
+    reference's writers store an `int` with sizeof(size_t) -- cols in ConjugateGradient_CPU_OMP.hpp:206-210,
+    both words in ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:754-757 -- leaving garbage in the upper 32 bits, so
+    take the words as they are if the file is long enough for them, else their low halves if those fit."""
+    size = os.path.getsize(path)
+    esz = np.dtype(dtype).itemsize
     with open(path, "rb") as f:
         hdr = np.frombuffer(f.read(16), dtype=np.uint64)
-        if hdr.size != 2:
-            raise IOError("short header")
-        rows, cols = int(hdr[0]), int(hdr[1]) & 0xFFFFFFFF   # reference writes garbage in the top half
-    return rows, cols
+    if hdr.size != 2:
+        raise IOError("short header")
+    for rows, cols in ((int(hdr[0]), int(hdr[1])), (int(hdr[0]) & 0xFFFFFFFF, int(hdr[1]) & 0xFFFFFFFF)):
+        if rows > 0 and cols > 0 and rows * cols * esz <= size - 16:
+            return rows, cols
+    raise IOError("file is shorter than its header says")
 
 
 class Solver:
@@ -252,7 +260,7 @@ class Solver:
     # -- file mode (format: random_spd_system.cpp:105-121) ------------------------------------------
     def load_matrix_from_file(self, filename, chunk_bytes=256 << 20):
         try:
-            rows, cols = _read_bin(filename, self.mat_host_dtype)
+            rows, cols = _read_bin(filename, np.float64 if self.dtype == F64 else np.float32)
         except OSError:
             return False
         if rows != cols:
@@ -272,7 +280,7 @@ class Solver:
 
     def load_rhs_from_file(self, filename):
         try:
-            rows, cols = _read_bin(filename, self.vec_dtype)
+            rows, cols = _read_bin(filename, np.float64 if self.dtype == F64 else np.float32)
         except OSError:
             return False
         if cols != 1 or rows != self.n:

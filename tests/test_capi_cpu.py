@@ -65,3 +65,43 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
                         "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_file_header_rule_is_the_same_in_cpp_and_python(lam, tmp_path):
+    """One header rule for every loader: the reference's writers leave garbage in the upper
+    32 bits of cols (ConjugateGradient_CPU_OMP.hpp:206-210) or of BOTH words (ConjugateGradient_MultiGPUS_
+    CUDA_NCCL.cu:754-757).  LAM::parse_bin_header (C++ loaders) and _capi._read_bin (Python loaders) must
+    accept and reject the same files."""
+    import importlib, subprocess
+    import numpy as np
+    capi = importlib.import_module("2024-eumaster4hpc-student-challenge_amd._capi")
+    G = 0x2E00B50000000000                      # the garbage pattern observed in reference-written files
+    cases = {                                    # name: (hdr words, payload elements, expected (rows, cols) or None)
+        "clean_matrix": ((8, 8), 64, (8, 8)),
+        "clean_vector": ((8, 1), 8, (8, 1)),
+        "garbage_cols": ((8, G | 1), 8, (8, 1)),
+        "garbage_both": ((G | 8, G | 1), 8, (8, 1)),
+        "truncated": ((8, 8), 60, None),
+        "longer_than_needed": ((4, 1), 8, (4, 1)),
+        "zero_rows": ((0, 1), 8, None),
+    }
+    src = tmp_path / "hdr.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "LAM.hpp"\n'
+                   'int main(int c, char **v) { uint64_t h[2] = {strtoull(v[1], 0, 0), strtoull(v[2], 0, 0)}, r = 0, k = 0;\n'
+                   '  bool ok = LAM::parse_bin_header(h, strtoull(v[3], 0, 0), 8, &r, &k);\n'
+                   '  if (ok) printf("%llu %llu\\n", (unsigned long long)r, (unsigned long long)k); else printf("bad\\n"); return 0; }\n')
+    exe = tmp_path / "hdr.out"
+    pkg = os.path.join(ROOT, "2024-eumaster4hpc-student-challenge_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-DUSE_HIP", "-I", os.path.join(pkg, "LAM", "include"), "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for name, (hdr, nelem, want) in cases.items():
+        f = tmp_path / (name + ".bin")
+        f.write_bytes(np.array(hdr, dtype=np.uint64).tobytes() + np.zeros(nelem).tobytes())
+        out = subprocess.run([str(exe), hex(hdr[0]), hex(hdr[1]), str(16 + 8 * nelem)], capture_output=True, text=True).stdout.strip()
+        got_cpp = None if out == "bad" else tuple(int(x) for x in out.split())
+        try:
+            got_py = capi._read_bin(str(f), np.float64)
+        except OSError:
+            got_py = None
+        assert got_cpp == want and got_py == want, (name, got_cpp, got_py, want)
