@@ -32,6 +32,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/lam_hip.h"
 #include "lam_kernels.h"
 
@@ -112,6 +114,17 @@ struct lam_hip_ctx {
     int64_t opt_finalize = 1;      // several shards: 1 = producer kernels reduce their partials themselves (Finalize);
                                    // 0 = separate 1-block finalize_sum_kernel launches (A/B measurements)
     uint64_t n_collectives = 0;    // RCCL calls enqueued by this context (diagnostics: must match across ranks)
+    // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
+    Mail *mail = nullptr;                       // own mailbox, fine-grained device memory
+    Mail *peer_mail[kMaxShards] = {};           // every rank's mailbox as seen from here (own included)
+    void *peer_p[kMaxShards] = {};              // every rank's p replica as seen from here (own included)
+    void *ipc_opened[2 * kMaxShards] = {};      // mappings to close again
+    int n_ipc_opened = 0;
+    uint64_t problem_gen = 0, direct_gen = ~0ull;   // direct mappings belong to one set_problem generation
+    bool direct_ok = false;
+    bool cg_direct = false;                     // the current CG state runs on the direct exchange
+    uint32_t epoch = 0;                         // bumped by every cg_init: mailbox tags never repeat
+    int *direct_err = nullptr;                  // pinned host: a bounded wait of the direct exchange expired
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
     // the symmetric product exists for one shard, fp64/fp32 storage, n a multiple of its column tile
@@ -122,6 +135,7 @@ struct lam_hip_ctx {
     }
 
     // gather-Ap needs equal slices and an 8-byte aligned tail for the double
+    bool exchange2_wanted() const { return rank_mode && opt_exchange == 2 && opt_finalize != 0; }
     bool exchange1_ok() const
     {
         return rank_mode && opt_exchange == 1 && n % (uint64_t)nranks == 0 && ((n / (uint64_t)nranks) * esz_v()) % 8 == 0;
@@ -324,7 +338,7 @@ struct Impl {
         GemvArgs<TA, TV> a;
         a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
         if (fin != nullptr && partial != nullptr) a.fin = *fin;
-        else { a.fin.active = 0; a.fin.dst.n = 0; a.fin.slot = 0; }
+        else { a.fin.active = 0; a.fin.mail = 0; a.fin.seq = 0; a.fin.dst.n = 0; a.fin.slot = 0; }
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
         a.seg_begin[0] = 0; a.seg_end[0] = c->n; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
         if (panel == 1) { a.seg_begin[0] = lo; a.seg_end[0] = hi; }
@@ -538,6 +552,8 @@ Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
 {
     Finalize f;
     f.active = 0;
+    f.mail = 0;
+    f.seq = 0;
     f.dst.n = 0;
     f.slot = s.index;
     if (!c->rank_mode && c->total_shards == 1) return f;
@@ -685,6 +701,172 @@ int arm_partials(lam_hip_ctx *c)
     return 0;
 }
 
+MailPost no_post()
+{
+    MailPost p;
+    p.n = 0; p.rank = 0; p.seq = 0;
+    for (auto &m : p.mail) m = nullptr;
+    return p;
+}
+
+// ---- direct exchange (option exchange = 2) --------------------------------------------------------
+void close_direct(lam_hip_ctx *c)
+{
+    for (int i = 0; i < c->n_ipc_opened; i++) (void)hipIpcCloseMemHandle(c->ipc_opened[i]);
+    c->n_ipc_opened = 0;
+    c->direct_ok = false;
+    c->direct_gen = ~0ull;
+}
+
+// What a rank tells the others about its buffers.  Same process (ranks as threads): the pointers are
+// used as they are; another process: the HIP IPC handles are opened.
+struct DirectHello {
+    int pid, dev;
+    void *p, *mail;
+    hipIpcMemHandle_t hp, hm;
+    int have_handles;
+};
+
+// Collective: every rank must call it the same number of times (it is part of lam_hip_cg_init).  Ends
+// with an agreement, so either all ranks use the direct exchange or none does.
+int setup_direct(lam_hip_ctx *c)
+{
+    if (c->direct_gen == c->problem_gen) return 0;
+    close_direct(c);
+    ShardBase &s = c->sh[0];
+    LAMCHK(set_dev(c, s));
+    bool ok = true;
+    if (c->mail == nullptr) {
+        // fine-grained memory: polled by this rank's kernels while peers write it over xGMI
+        if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); c->mail = nullptr; ok = false; }
+        }
+        if (c->mail) HIPCHK(c, hipMemset(c->mail, 0, sizeof(Mail)));
+        if (c->direct_err == nullptr) {
+            HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));
+            *c->direct_err = 0;
+        }
+    }
+    const int P = c->nranks;
+    constexpr size_t kRec = 256;
+    static_assert(sizeof(DirectHello) <= kRec, "hello record");
+    DevBuf dev;
+    HIPCHK(c, hipMalloc(&dev.p, kRec * (size_t)P));
+    std::vector<char> host(kRec * (size_t)P, 0);
+    DirectHello me;
+    memset(&me, 0, sizeof me);
+    me.pid = (int)getpid();
+    me.dev = s.dev;
+    me.p = s.p;
+    me.mail = c->mail;
+    me.have_handles = ok && hipIpcGetMemHandle(&me.hp, s.p) == hipSuccess && hipIpcGetMemHandle(&me.hm, c->mail) == hipSuccess;
+    (void)hipGetLastError();
+    memcpy(host.data() + kRec * (size_t)c->rank, &me, sizeof me);
+    HIPCHK(c, hipMemcpyAsync((char *)dev.p + kRec * (size_t)c->rank, host.data() + kRec * (size_t)c->rank, kRec, hipMemcpyHostToDevice, s.stream));
+    NCCLCHK(c, ncclAllGather((char *)dev.p + kRec * (size_t)c->rank, dev.p, kRec, ncclChar, c->comm, s.stream));
+    c->n_collectives++;
+    HIPCHK(c, hipMemcpyAsync(host.data(), dev.p, kRec * (size_t)P, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(c, hipStreamSynchronize(s.stream));
+    for (int q = 0; q < P && ok; q++) {
+        DirectHello h;
+        memcpy(&h, host.data() + kRec * (size_t)q, sizeof h);
+        if (q == c->rank) { c->peer_p[q] = s.p; c->peer_mail[q] = c->mail; continue; }
+        if (h.mail == nullptr) { ok = false; break; }
+        if (h.pid == me.pid) {
+            // a thread of this process: same address space; another device needs peer access
+            if (h.dev != s.dev) {
+                hipError_t pe = hipDeviceEnablePeerAccess(h.dev, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                (void)hipGetLastError();
+            }
+            c->peer_p[q] = h.p;
+            c->peer_mail[q] = (Mail *)h.mail;
+        } else {
+            void *pp = nullptr, *pm = nullptr;
+            if (!h.have_handles || hipIpcOpenMemHandle(&pp, h.hp, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            c->ipc_opened[c->n_ipc_opened++] = pp;
+            if (hipIpcOpenMemHandle(&pm, h.hm, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+            c->ipc_opened[c->n_ipc_opened++] = pm;
+            c->peer_p[q] = pp;
+            c->peer_mail[q] = (Mail *)pm;
+        }
+    }
+    int all = 0;
+    LAMCHK(lam_hip_all_ok(c, ok ? 1 : 0, &all));
+    if (!all) close_direct(c);
+    c->direct_ok = all != 0;
+    c->direct_gen = c->problem_gen;
+    return 0;
+}
+
+int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TV = typename ImplTraits<I>::TV;
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const int P = c->nranks;
+        const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
+        // 1. GEMV.  p for this iteration: the own slice is local; the others were stored into this rank's
+        //    replica by the peers' update_p of iteration k-1 (k == 1: by cg_init) -- wait for their flags
+        //    behind the own-slice panel.
+        uint64_t lo = 0, hi = 0;
+        uint64_t a = s.row0, b = s.row0 + s.nrows;
+        if (P > 1 && (!I::fast_ok(c) || (a % I::VEC == 0 && b % I::VEC == 0))) { lo = a; hi = b; }
+        Finalize fa;
+        fa.active = 1; fa.mail = 1; fa.seq = seq; fa.slot = 0; fa.dst.n = P;
+        for (int q = 0; q < P; q++) fa.dst.p[q] = &c->peer_mail[q]->pap[c->rank];
+        BlockCounts nb;
+        for (int q = 0; q < kMaxShards; q++) {
+            uint64_t r0 = 0, nr = 0;
+            if (q < P) partition(c->n, P, q, &r0, &nr);
+            nb.n[q] = q < P ? vec_grid(nr) : 0;
+        }
+        const bool need_wait = P > 1 && k > 1;
+        s.split_slot[slot] = hi > lo;
+        if (hi > lo) {
+            HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, s.sc, 1, lo, hi));
+            HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+        }
+        if (need_wait) {
+            hipLaunchKernelGGL(wait_p_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const Mail *)c->mail, P, c->rank, nb, seq - 1,
+                               (const CgScalars *)s.sc, c->direct_err);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (hi > lo) {
+            HIPCHK(c, hipEventRecord(s.ev_g2[slot], s.stream));
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi, &fa));
+            HIPCHK(c, hipEventRecord(s.ev_g3[slot], s.stream));
+        } else {
+            HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 0, 0, 0, &fa));
+            HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+        }
+        // 2. x, r: waits in the kernel for the P partials of p.Ap; its reducer posts the r.r partial
+        Finalize fb = fa;
+        for (int q = 0; q < P; q++) fb.dst.p[q] = &c->peer_mail[q]->rr[c->rank];
+        hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
+                           (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
+                           MailWait{c->mail->pap, P, seq, c->direct_err});
+        HIPCHK(c, hipGetLastError());
+        // 3. stop test + p slice into every replica + flags
+        PtrList pl;
+        pl.n = P;
+        for (int q = 0; q < P; q++) pl.p[q] = c->peer_p[q];
+        MailPost post = no_post();
+        post.n = P; post.rank = c->rank; post.seq = seq;
+        for (int q = 0; q < P; q++) post.mail[q] = c->peer_mail[q];
+        hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
+                           rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows, (volatile int *)s.host_flags,
+                           MailWait{c->mail->rr, P, seq, c->direct_err}, post);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    });
+}
+
 // gather-Ap exchange: CG state = x slice, FULL r and p on every rank
 int do_cg_init_exchange1(lam_hip_ctx *c)
 {
@@ -722,6 +904,7 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         //    behind the slice (with option "finalize" = 0: a 1-block launch does)
         Finalize f;
         f.active = c->opt_finalize ? 1 : 0;
+        f.mail = 0; f.seq = 0;
         f.dst.n = 1; f.dst.p[0] = rec + base * sizeof(TV); f.slot = 0;
         HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
         LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc, 0, 0, 0, &f));
@@ -749,6 +932,14 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
 
 int do_cg_init(lam_hip_ctx *c)
 {
+    c->cg_direct = false;
+    if (c->exchange2_wanted()) {
+        // the state is initialised through RCCL (one-off); the iterations then run on the mailboxes
+        LAMCHK(setup_direct(c));
+        c->cg_direct = c->direct_ok;
+        c->epoch++;
+        if (c->direct_err) *c->direct_err = 0;
+    }
     if (c->exchange1_ok()) return do_cg_init_exchange1(c);
     c->cg_exchange1 = false;
     return dispatch(c, [&](auto impl) -> int {
@@ -778,6 +969,7 @@ int do_cg_init(lam_hip_ctx *c)
 
 int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
+    if (c->cg_direct) return enqueue_iteration_direct(c, k, rel_error, slot);
     if (c->cg_exchange1) return enqueue_iteration_exchange1(c, k, rel_error, slot);
     return dispatch(c, [&](auto impl) -> int {
         using I = decltype(impl);
@@ -823,7 +1015,8 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             red_source(c, s, false, true, &red, &nred);
             const Finalize fb = make_finalize(c, s, true);
             hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + (fb.active ? 1 : 0)), dim3(kBlock), 0, s.stream, red, nred,
-                               s.sc, k, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb);
+                               s.sc, k, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
+                               MailWait{nullptr, 0, 0, nullptr});
             HIPCHK(c, hipGetLastError());
         }
         LAMCHK(reduce_step(c, true, false, true, fin));
@@ -835,7 +1028,7 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             red_source(c, s, true, false, &red, &nred);
             hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
                                rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows,
-                               (volatile int *)s.host_flags);
+                               (volatile int *)s.host_flags, MailWait{nullptr, 0, 0, nullptr}, no_post());
             HIPCHK(c, hipGetLastError());
         }
         LAMCHK(gather_p_step(c));
@@ -949,6 +1142,9 @@ void lam_hip_destroy(lam_hip_ctx *c)
         (void)hipSetDevice(s.dev);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
+    close_direct(c);
+    if (c->mail) (void)hipFree(c->mail);
+    if (c->direct_err) (void)hipHostFree(c->direct_err);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (auto &s : c->sh) {
         free_shard(s);
@@ -963,6 +1159,7 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
     if (n == 0) return fail(c, LAM_HIP_EINVAL, "n must be > 0");
     if (n < (uint64_t)c->total_shards) return fail(c, LAM_HIP_EINVAL, "n (%llu) smaller than the number of shards", (unsigned long long)n);
     c->n = n;
+    c->problem_gen++;              // peers' mappings of the old p replica are stale from here on
     c->have_problem = c->have_matrix = c->have_rhs = c->cg_ready = false;
     const size_t ea = c->esz_a(), ev = c->esz_v();
     for (auto &s : c->sh) {
@@ -1265,6 +1462,9 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     }
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
+    if (c->cg_direct && c->direct_err && *c->direct_err != 0)
+        return fail(c, LAM_HIP_EHIP, "direct exchange: a bounded wait for a peer expired (code %d: 2 = partial dot product, 3 = p slice); "
+                                     "the ranks are no longer in step", *c->direct_err);
     // harvest the GEMV timings still in the ring
     for (int j = std::max(0, enq - kLag); j < enq; j++) harvest(j % kLag);
     LAMCHK(set_dev(c, s0));
@@ -1666,7 +1866,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
     else if (!strcmp(name, "symmetric")) *value = c->opt_symmetric;
     else if (!strcmp(name, "symmetric_effective")) *value = c->symv_active() ? 1 : 0;
-    else if (!strcmp(name, "exchange_effective")) *value = c->exchange1_ok() ? 1 : 0;
+    else if (!strcmp(name, "exchange_effective")) *value = c->cg_direct ? 2 : ((c->exchange1_ok() && !c->exchange2_wanted()) ? 1 : 0);
     else if (!strcmp(name, "panel_lo")) *value = c->opt_panel_lo;
     else if (!strcmp(name, "panel_hi")) *value = c->opt_panel_hi;
     else return LAM_HIP_EINVAL;

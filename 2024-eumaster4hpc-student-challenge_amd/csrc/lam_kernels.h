@@ -112,14 +112,79 @@ struct PtrList {                      // destinations of a replicated store (one
 // (An arrival counter drawn by every workgroup -- store, drain, fetch_add -- was measured first: the
 // two memory round trips at the end of each of 11584 GEMV workgroups cost 45 us per launch, four times
 // what the removed launch had cost.)
-struct Finalize {
-    int active;                       // 0: no in-kernel reduction (the launch has no reducer workgroup)
-    PtrList dst;
-    int slot;
-};
 constexpr unsigned long long kPartialSentinel = 0x7ff8dead5eedbeefull;   // quiet NaN with a payload nothing computes
 constexpr unsigned long long kFinalizeTimeoutTicks = 5ull * 100000000ull; // wall_clock64() runs at 100 MHz: 5 s
 
+struct Finalize {
+    int active;                       // 0: no in-kernel reduction (the launch has no reducer workgroup)
+    int mail;                         // 1: dst.p[j] is a MailSlot of rank j's mailbox (direct exchange, see Mail)
+    PtrList dst;
+    int slot;
+    unsigned long long seq;           // mail: the iteration tag
+};
+
+// ---------------------------------------------------------------------------------------------
+// Direct exchange (rank mode, option exchange = 2): no collective call inside the
+// iteration.  Every rank maps every other rank's p replica and MAILBOX (HIP IPC, or plain pointers when
+// the ranks are threads of one process) and the producer kernels store straight into them over xGMI:
+//   * the reducer workgroup of the GEMV / update_xr launch writes the rank's partial dot product into
+//     slot [rank] of EVERY rank's mailbox: value (system-scope write-through store), drain, then the tag
+//     `seq` = (solve epoch << 32) | iteration.  The consumer kernel (update_xr / update_p) polls the P tags
+//     of its own mailbox and sums the P values in rank order: the fused, latency-optimal form of the two
+//     scalar all-reduces, deterministic and bit-identical to the RCCL exchange;
+//   * update_p stores its p slice into every rank's p replica with system-scope write-through stores,
+//     drains them, and raises pflag[rank][workgroup] = seq in every mailbox; a 1-workgroup wait_p_kernel
+//     in front of the next GEMV (behind its own-slice panel) polls those flags: the direct all-gather.
+// Mailboxes are fine-grained (uncached) device memory; tags never repeat (epoch), so nothing is ever
+// reset and a slot can be read by any number of workgroups.  Every poll is bounded (kFinalizeTimeoutTicks):
+// a peer that never shows up ends in an error flag in pinned host memory, not in a hang.
+// ---------------------------------------------------------------------------------------------
+struct MailSlot {
+    unsigned long long value_bits;    // the double, written first
+    unsigned long long seq;           // written after the value has been drained to memory
+};
+struct Mail {
+    MailSlot pap[kMaxShards];
+    MailSlot rr[kMaxShards];
+    unsigned long long pflag[kMaxShards][256];   // [source rank][its update_p workgroup] (256 == kVecBlocksMax)
+};
+struct MailWait {                     // consumer side of a scalar exchange; n == 0: not used
+    const MailSlot *slots;            // this rank's pap[] or rr[]
+    int n;
+    unsigned long long seq;
+    int *host_err;                    // pinned host memory
+};
+struct MailPost {                     // update_p: flags to raise after the p slice has been stored; n == 0: not used
+    Mail *mail[kMaxShards];
+    int n, rank;
+    unsigned long long seq;
+};
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Sum of the P partials other ranks posted for iteration `w.seq`; every thread of every workgroup gets the
+// same value.  Same reduction tree as block_sum_array(src, P), so exchange 2 and exchange 0 agree bit for bit.
+__device__ __forceinline__ double mail_sum(const MailWait &w, double *s_red)
+{
+    double v = 0.0;
+    if ((int)threadIdx.x < w.n) {
+        const MailSlot *m = w.slots + threadIdx.x;
+        const unsigned long long t0 = wall_clock64();
+        while (ld_sys(&m->seq) != w.seq) {
+            if (wall_clock64() - t0 > kFinalizeTimeoutTicks) { *w.host_err = 2; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        v = __longlong_as_double((long long)ld_sys(&m->value_bits));
+    }
+    return block_sum(v, s_red);
+}
 __device__ __forceinline__ bool is_reducer_block(const Finalize &f) { return f.active && blockIdx.x == gridDim.x - 1; }
 __device__ __forceinline__ unsigned compute_blocks(const Finalize &f) { return gridDim.x - (f.active ? 1u : 0u); }
 
@@ -176,8 +241,17 @@ __device__ __forceinline__ void reduce_partials(double *partial, const Finalize 
         v += a[0];
     }
     const double total = block_sum(v, s_red);
-    if (threadIdx.x == 0)
-        for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
+    if (threadIdx.x == 0) {
+        if (!f.mail) {
+            for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
+        } else {
+            // direct exchange: value into every rank's mailbox, drain, then the tags
+            for (int j = 0; j < f.dst.n; j++)
+                st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->value_bits, (unsigned long long)__double_as_longlong(total));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int j = 0; j < f.dst.n; j++) st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->seq, f.seq);
+        }
+    }
 }
 
 // arm the slots (cg_init, and whenever a launch without a reducer may have written plain values)
@@ -922,12 +996,12 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
                  const TV *__restrict__ p_loc, const TV *__restrict__ Ap, TV *__restrict__ x,
-                 TV *__restrict__ r, uint64_t n_loc, double *__restrict__ partial, Finalize fin)
+                 TV *__restrict__ r, uint64_t n_loc, double *__restrict__ partial, Finalize fin, MailWait mw)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
     if (is_reducer_block(fin)) { reduce_partials(partial, fin, s_red); return; }
-    const double pAp = block_sum_array(red, nred, s_red);
+    const double pAp = mw.n > 0 ? mail_sum(mw, s_red) : block_sum_array(red, nred, s_red);
     const double rr = sc->rr[(k + 1) & 1];
     const double alpha_d = rr / pAp;
     const TV alpha = (TV)alpha_d;
@@ -950,11 +1024,12 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
                 const TV *__restrict__ r, const TV *__restrict__ p_loc, PtrList pdst, uint64_t row0,
-                uint64_t n_loc, volatile int *host_flags /* pinned host: [0]=iters [1]=stopping iteration (0 = none) */)
+                uint64_t n_loc, volatile int *host_flags /* pinned host: [0]=iters [1]=stopping iteration (0 = none) */,
+                MailWait mw, MailPost post)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
-    const double rr_new = block_sum_array(red, nred, s_red);
+    const double rr_new = mw.n > 0 ? mail_sum(mw, s_red) : block_sum_array(red, nred, s_red);
     const double rr = sc->rr[(k + 1) & 1];
     const double bb = sc->bb;
     const double beta_d = rr_new / rr;
@@ -975,9 +1050,41 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
         return;
     }
     const TV beta = (TV)beta_d;
+    if (post.n == 0) {
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock) {
+            const TV pi = r[i] + beta * p_loc[i];
+            for (int j = 0; j < pdst.n; j++) reinterpret_cast<TV *>(pdst.p[j])[row0 + i] = pi;
+        }
+        return;
+    }
+    // direct exchange: the slice goes into every rank's replica with system-scope (write-through) stores;
+    // once this workgroup's stores have drained it raises its flag in every mailbox
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += (uint64_t)gridDim.x * kBlock) {
         const TV pi = r[i] + beta * p_loc[i];
-        for (int j = 0; j < pdst.n; j++) reinterpret_cast<TV *>(pdst.p[j])[row0 + i] = pi;
+        for (int j = 0; j < pdst.n; j++)
+            __hip_atomic_store(reinterpret_cast<TV *>(pdst.p[j]) + row0 + i, pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)threadIdx.x < post.n && (int)threadIdx.x != post.rank)
+        st_sys(&post.mail[threadIdx.x]->pflag[post.rank][blockIdx.x], post.seq);
+}
+
+// direct exchange: wait until every other rank's update_p workgroups have flagged their p slice for `seq`
+struct BlockCounts { int n[kMaxShards]; };
+__global__ void __launch_bounds__(kBlock)
+wait_p_kernel(const Mail *mine, int nranks, int rank, BlockCounts nb, unsigned long long seq, const CgScalars *sc, int *host_err)
+{
+    if (sc->stop) return;
+    const unsigned long long t0 = wall_clock64();
+    for (int q = 0; q < nranks; q++) {
+        if (q == rank) continue;
+        for (int b = threadIdx.x; b < nb.n[q]; b += kBlock) {
+            while (ld_sys(&mine->pflag[q][b]) != seq) {
+                if (wall_clock64() - t0 > kFinalizeTimeoutTicks) { *host_err = 3; return; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
     }
 }
 

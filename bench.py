@@ -227,6 +227,29 @@ def main():
                     (base + "RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration on one stream (no overlap)",))
         runs.append(timed("allgather_Ap", exchange=1, overlap=1) +
                     (base + "ONE RCCL all-gather of [Ap slice | p.Ap partial] per iteration (full-length r, p per rank)",))
+        # Last, because a failure here leaves the ranks out of step: the direct exchange (peer-mapped
+        # mailboxes, no collective call inside the iteration).  A rank that cannot map its peers falls back to
+        # exchange 0 (all ranks agree); a bounded wait that expires raises -- then nothing collective follows.
+        try:
+            s.set_option("exchange", 2)
+            s.set_option("overlap", 1)
+            s.cg_init()
+            if s.get_option("exchange_effective") != 2:
+                raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
+            if args.warmup > 0:
+                s.cg_iterate(args.warmup, 0.0)
+            barrier()
+            t0_ = time.perf_counter()
+            st_ = s.cg_iterate(args.steps, 0.0)
+            barrier()
+            dt_, st_ = max_over_ranks(time.perf_counter() - t0_, st_)
+            res_ = s.true_residual()
+            exchange_modes["direct_mailboxes"] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
+                                                  "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_}
+            runs.append((dt_, st_, res_, base + "direct stores into peer-mapped mailboxes and p replicas over xGMI "
+                                                "(no collective call inside the iteration)"))
+        except Exception as e:   # noqa: BLE001
+            exchange_modes["direct_mailboxes"] = {"error": str(e)[:300]}
         dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])
     n_coll = s.get_option("collectives_enqueued")
 

@@ -197,7 +197,12 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   ncclAllGather(p slices) -- sliced x, r, Ap, replicated p.  1: ONE ncclAllGather of
  *                   [Ap slice | p.Ap partial] per iteration, r and p kept full-length on every rank and
  *                   updated redundantly (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505); needs
- *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  Re-run cg_init/solve
+ *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  2: DIRECT exchange, no
+ *                   collective call inside the iteration: every rank maps the other ranks' p replicas and
+ *                   mailboxes (HIP IPC; set up once per problem through the communicator) and the kernels store
+ *                   their partial dot products and p slices straight into them over xGMI, tagged with the
+ *                   iteration; consumers poll the tags (bounded).  Results are bit-identical to exchange 0.
+ *                   Falls back to 0 when a mapping cannot be made (all ranks agree).  Re-run cg_init/solve
  *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts.
  *   "symmetric"     single shard, fp64/fp32, N a multiple of 4096 (fp64) / 8192 (fp32): 1 = the matrix-vector
  *                   product reads only the upper triangle (A must equal its transpose, which CG requires

@@ -3,11 +3,11 @@
 LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl_async.hip: stream-ordered, nothing
 synchronises hosts or streams -- the semantics of the real library).  Prints one JSON line.
 
-usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1] [--finalize 0|1] [--iters K] [--tol T]
+usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1] [--iters K] [--tol T]
                              [--chunk C]    with mode in {tridiag, spd}
 --chunk C runs the solve as repeated lam_hip_cg_iterate(C) calls (the stop has to be noticed across
 calls, and every rank must leave the loop after the same call)."""
-import argparse, importlib, json, os, sys, threading
+import argparse, hashlib, importlib, json, os, sys, threading
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -67,7 +67,8 @@ def main():
                 res = s.true_residual()          # collective
                 y = s.gemv(xprobe)               # collective
                 out[r] = dict(conv=conv, iters=s.stats["num_iters"], err=s.stats["rel_err"], x=x, res=res, y=y,
-                              part=s.partition(r), ncoll=s.get_option("collectives_enqueued"), calls=calls)
+                              part=s.partition(r), ncoll=s.get_option("collectives_enqueued"), calls=calls,
+                              eff=s.get_option("exchange_effective"))
         except Exception as e:                   # noqa: BLE001
             errs.append(f"rank {r}: {e!r}")
 
@@ -84,6 +85,7 @@ def main():
         "P": P, "n": n, "iters": out[0]["iters"], "converged": bool(out[0]["conv"]), "true_residual": out[0]["res"],
         "rel_err": out[0]["err"], "partition": [list(o["part"]) for o in out],
         "collectives_enqueued": [o["ncoll"] for o in out], "iterate_calls": [o["calls"] for o in out],
+        "exchange_effective": [o["eff"] for o in out], "x_sha": hashlib.sha256(out[0]["x"].tobytes()).hexdigest(),
         "ranks_identical": bool(all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"]
                                     and o["err"] == out[0]["err"] and np.array_equal(out[0]["y"], o["y"]) for o in out)),
     }

@@ -79,11 +79,36 @@ def _check_solution(out, P, n, mode):
     (4, 4096, "spd", 1, 1),
     (8, 8192, "spd", 1, 1),
     (3, 1001, "tridiag", 1, 1),     # uneven split: falls back to exchange 0
+    # exchange = 2: direct stores into peer-mapped mailboxes and p replicas, no collective in the iteration
+    (2, 1024, "tridiag", 1, 2),
+    (4, 4096, "spd", 1, 2),
+    (8, 8192, "spd", 1, 2),
+    (3, 1001, "tridiag", 1, 2),     # odd N (generic kernel), uneven split
+    (4, 4102, "spd", 1, 2),         # odd row offsets: the GEMV is not split
 ])
 def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, overlap, exchange):
     r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--overlap", overlap, "--exchange", exchange)
     _check_mock_stats(lines, P)
     _check_solution(out, P, n, mode)
+    if exchange == 2:
+        assert out["exchange_effective"] == [2] * P, out
+        # set-up and the collective checks after the solve go through the communicator, the iterations do not
+        assert out["collectives_enqueued"][0] < 40 + 4 * P, out
+
+
+@pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), (4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
+def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path, P, n, mode):
+    """exchange 2 sums the ranks' partial dot products with the same reduction tree as exchange 0, so the
+    two must produce the same bits: iteration count, residual and every element of x."""
+    outs = []
+    for ex in (0, 2):
+        r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--exchange", ex, "--no-single")
+        _check_mock_stats(lines, P)
+        os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
+        outs.append(out)
+    a, b = outs
+    assert b["exchange_effective"] == [2] * P
+    assert (a["iters"], a["rel_err"], a["x_sha"]) == (b["iters"], b["rel_err"], b["x_sha"]), (a, b)
 
 
 @pytest.mark.parametrize("P,n,mode,exchange,delay,chunk", [
@@ -104,6 +129,11 @@ def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, ov
     # the solve split over several lam_hip_cg_iterate calls: the stop must also be agreed on across calls
     (4, 2048, "tridiag", 0, "1:100", 7),
     (2, 1024, "tridiag", 1, "", 5),
+    # the direct exchange under the same stresses
+    (4, 2048, "tridiag", 2, "", 0),
+    (8, 4096, "spd", 2, "3:100,6:250", 0),
+    (4, 32768, "spd", 2, "", 0),
+    (4, 2048, "tridiag", 2, "1:100", 7),
 ])
 def test_stop_protocol_keeps_ranks_in_step(mock_async, tmp_path, P, n, mode, exchange, delay, chunk):
     """Convergence under asynchronous collectives: all ranks must enqueue the same number of collectives
@@ -165,9 +195,10 @@ def _check_bench_line(r, nproc):
     out = json.loads(lines[0])
     assert out["n_gpus"] == nproc and out["steps"] == 20 and out["scaling"] == "strong" and out["dtype"] == "f64"
     assert out["metric"] == "cg_iterations_per_sec" and out["value"] > 0
-    assert set(out["exchange_modes"]) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap"}
+    assert set(out["exchange_modes"]) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap",
+                                          "direct_mailboxes"}
     for m in out["exchange_modes"].values():
-        assert m["value"] > 0
+        assert m.get("value", 0) > 0, out["exchange_modes"]
     # both exchanges solved the same problem: true residuals agree (different rounding only)
     res = [m["rel_residual_true"] for m in out["exchange_modes"].values()]
     assert all(abs(r_ / res[0] - 1) < 1e-6 for r_ in res)
