@@ -125,6 +125,7 @@ struct lam_hip_ctx {
     bool cg_direct = false;                     // the current CG state runs on the direct exchange
     uint32_t epoch = 0;                         // bumped by every cg_init: mailbox tags never repeat
     int *direct_err = nullptr;                  // pinned host: a bounded wait of the direct exchange expired
+    double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
     // the symmetric product exists for one shard, fp64/fp32 storage, n a multiple of its column tile
@@ -745,14 +746,15 @@ int setup_direct(lam_hip_ctx *c)
         if (c->mail) HIPCHK(c, hipMemset(c->mail, 0, sizeof(Mail)));
         if (c->direct_err == nullptr) {
             HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));
-            *c->direct_err = 0;
+            memset(c->direct_err, 0, 64);
         }
     }
     const int P = c->nranks;
     constexpr size_t kRec = 256;
     static_assert(sizeof(DirectHello) <= kRec, "hello record");
-    DevBuf dev;
-    HIPCHK(c, hipMalloc(&dev.p, kRec * (size_t)P));
+    static_assert(kRec * kMaxShards <= 4096, "hello records fit the set-up scratch");
+    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, 4096));
+    struct { void *p; } dev{c->agree_buf};       // kept for the life of the context (no hipFree in a collective path)
     std::vector<char> host(kRec * (size_t)P, 0);
     DirectHello me;
     memset(&me, 0, sizeof me);
@@ -938,7 +940,7 @@ int do_cg_init(lam_hip_ctx *c)
         LAMCHK(setup_direct(c));
         c->cg_direct = c->direct_ok;
         c->epoch++;
-        if (c->direct_err) *c->direct_err = 0;
+        if (c->direct_err) memset(c->direct_err, 0, 64);
     }
     if (c->exchange1_ok()) return do_cg_init_exchange1(c);
     c->cg_exchange1 = false;
@@ -1143,6 +1145,7 @@ void lam_hip_destroy(lam_hip_ctx *c)
         if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
     close_direct(c);
+    if (c->agree_buf) (void)hipFree(c->agree_buf);
     if (c->mail) (void)hipFree(c->mail);
     if (c->direct_err) (void)hipHostFree(c->direct_err);
     if (c->comm) (void)ncclCommDestroy(c->comm);
@@ -1447,6 +1450,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             LAMCHK(set_dev(c, s0));
             HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
             harvest(slot);
+            if (c->cg_direct && *(volatile int *)c->direct_err != 0) break;     // reported after the sync below
             const int stop_at = ((volatile int *)s0.host_flags)[1];
             // LAM_HIP_DEBUG_LEVEL_STOP: test hook that restores the timing-dependent decision ("any stop
             // seen so far") so that the stream-ordered RCCL test double can be shown to catch the rank
@@ -1463,8 +1467,9 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
     if (c->cg_direct && c->direct_err && *c->direct_err != 0)
-        return fail(c, LAM_HIP_EHIP, "direct exchange: a bounded wait for a peer expired (code %d: 2 = partial dot product, 3 = p slice); "
-                                     "the ranks are no longer in step", *c->direct_err);
+        return fail(c, LAM_HIP_EHIP, "direct exchange: rank %d: a bounded wait for a peer expired (code %d: 2 = partial dot product, 3 = p slice; "
+                                     "slot %d, expected tag %d:%d, saw %d:%d); the ranks are no longer in step", c->rank, c->direct_err[0],
+                    c->direct_err[1], c->direct_err[4], c->direct_err[2], c->direct_err[5], c->direct_err[3]);
     // harvest the GEMV timings still in the ring
     for (int j = std::max(0, enq - kLag); j < enq; j++) harvest(j % kLag);
     LAMCHK(set_dev(c, s0));
@@ -1796,13 +1801,14 @@ int lam_hip_all_ok(lam_hip_ctx *c, int local_ok, int *global_ok)
     if (!c->rank_mode) return 0;
     ShardBase &s = c->sh[0];
     LAMCHK(set_dev(c, s));
-    DevBuf buf;
-    HIPCHK(c, hipMalloc(&buf.p, sizeof(double)));
+    // No hipMalloc/hipFree here: hipFree waits for the whole device, and when the ranks are threads of one
+    // process (the test double) that includes peers' kernels that are waiting for THIS rank's next call.
+    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, 4096));
     double v = local_ok ? 0.0 : 1.0;       // number of ranks that failed
-    HIPCHK(c, hipMemcpyAsync(buf.p, &v, sizeof v, hipMemcpyHostToDevice, s.stream));
-    NCCLCHK(c, ncclAllReduce(buf.p, buf.p, 1, ncclDouble, ncclSum, c->comm, s.stream));
+    HIPCHK(c, hipMemcpyAsync(c->agree_buf, &v, sizeof v, hipMemcpyHostToDevice, s.stream));
+    NCCLCHK(c, ncclAllReduce(c->agree_buf, c->agree_buf, 1, ncclDouble, ncclSum, c->comm, s.stream));
     c->n_collectives++;
-    HIPCHK(c, hipMemcpyAsync(&v, buf.p, sizeof v, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(c, hipMemcpyAsync(&v, c->agree_buf, sizeof v, hipMemcpyDeviceToHost, s.stream));
     HIPCHK(c, hipStreamSynchronize(s.stream));
     *global_ok = v == 0.0 ? 1 : 0;
     return 0;

@@ -177,8 +177,16 @@ __device__ __forceinline__ double mail_sum(const MailWait &w, double *s_red)
     if ((int)threadIdx.x < w.n) {
         const MailSlot *m = w.slots + threadIdx.x;
         const unsigned long long t0 = wall_clock64();
-        while (ld_sys(&m->seq) != w.seq) {
-            if (wall_clock64() - t0 > kFinalizeTimeoutTicks) { *w.host_err = 2; break; }
+        unsigned long long seen;
+        while ((seen = ld_sys(&m->seq)) != w.seq) {
+            // an expired wait anywhere (this kernel or an earlier one) ends all waiting: the solve has failed
+            if (*(volatile int *)w.host_err != 0) break;
+            if (wall_clock64() - t0 > kFinalizeTimeoutTicks) {
+                w.host_err[1] = (int)threadIdx.x; w.host_err[2] = (int)(unsigned)w.seq; w.host_err[3] = (int)(unsigned)seen;
+                w.host_err[4] = (int)(w.seq >> 32); w.host_err[5] = (int)(seen >> 32);
+                *(volatile int *)w.host_err = 2;
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
         }
         v = __longlong_as_double((long long)ld_sys(&m->value_bits));
@@ -1080,8 +1088,15 @@ wait_p_kernel(const Mail *mine, int nranks, int rank, BlockCounts nb, unsigned l
     for (int q = 0; q < nranks; q++) {
         if (q == rank) continue;
         for (int b = threadIdx.x; b < nb.n[q]; b += kBlock) {
-            while (ld_sys(&mine->pflag[q][b]) != seq) {
-                if (wall_clock64() - t0 > kFinalizeTimeoutTicks) { *host_err = 3; return; }
+            unsigned long long seen;
+            while ((seen = ld_sys(&mine->pflag[q][b])) != seq) {
+                if (*(volatile int *)host_err != 0) return;
+                if (wall_clock64() - t0 > kFinalizeTimeoutTicks) {
+                    host_err[1] = q * 1000 + b; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
+                    host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
+                    *(volatile int *)host_err = 3;
+                    return;
+                }
                 __builtin_amdgcn_s_sleep(4);
             }
         }
