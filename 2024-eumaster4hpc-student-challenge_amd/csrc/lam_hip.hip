@@ -499,9 +499,11 @@ int create_common(lam_hip_ctx *c)
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking) != hipSuccess)
             return fail(nullptr, LAM_HIP_EHIP, "hipStreamCreate failed on device %d", s.dev);
+        // cross-shard hand-over events: SYSTEM-scope release, so that a shard's stores into a peer device's
+        // p replica / gather array have left its L2 when the peer's stream passes the event
         hipEvent_t *evs[] = {&s.ev_a, &s.ev_b, &s.ev_p, &s.ev_gathered};
         for (auto ev : evs)
-            if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess)
+            if (hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
         for (int i = 0; i < kLag; i++) {
             if (hipEventCreateWithFlags(&s.ev_lag[i], hipEventDisableTiming) != hipSuccess ||
