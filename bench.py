@@ -144,6 +144,10 @@ def main():
 
     # the host driver on these nodes only supports dmabuf IPC; RCCL across processes needs this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one node (the contract: N GPUs of ONE node, rendezvous on 127.0.0.1): RCCL's bootstrap sockets go over
+    # the loopback interface instead of whatever interface the container happens to expose first
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     lam = importlib.import_module(PKG)
     lam.lib()
     use_dist = lam.launched_with_ranks()
@@ -231,6 +235,8 @@ def main():
         # mailboxes, no collective call inside the iteration).  A rank that cannot map its peers falls back to
         # exchange 0 (all ranks agree); a bounded wait that expires raises -- then nothing collective follows.
         try:
+            if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
+                raise RuntimeError("skipped (LAM_BENCH_DIRECT=0)")
             s.set_option("exchange", 2)
             s.set_option("overlap", 1)
             s.cg_init()
@@ -245,9 +251,15 @@ def main():
             dt_, st_ = max_over_ranks(time.perf_counter() - t0_, st_)
             res_ = s.true_residual()
             exchange_modes["direct_mailboxes"] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
-                                                  "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_}
-            runs.append((dt_, st_, res_, base + "direct stores into peer-mapped mailboxes and p replicas over xGMI "
-                                                "(no collective call inside the iteration)"))
+                                                  "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_,
+                                                  "rel_residual_recursive": st_["rel_err"]}
+            # a candidate for the headline only if it solved the same problem: all exchanges are deterministic
+            # and agree to rounding, and the recomputed residual must match the recursive one
+            if abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / runs[0][2] - 1) < 1e-6:
+                runs.append((dt_, st_, res_, base + "direct stores into peer-mapped mailboxes and p replicas over xGMI "
+                                                    "(no collective call inside the iteration)"))
+            else:
+                exchange_modes["direct_mailboxes"]["error"] = "residual differs from the RCCL exchanges: not used as the headline"
         except Exception as e:   # noqa: BLE001
             exchange_modes["direct_mailboxes"] = {"error": str(e)[:300]}
         dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])

@@ -190,6 +190,36 @@ def test_mpi_bootstrapped_driver_multi_rank(tmp_path, mock_mp_lib, mock_async, n
         assert len(lines) == nranks and all(l["abort"] == 0 for l in lines) and len({l["calls"] for l in lines}) == 1, lines
 
 
+@pytest.mark.parametrize("exchange", ["1", "2"])
+def test_mpi_driver_other_exchanges_across_processes(tmp_path, mock_async, exchange):
+    """LAM_HIP_EXCHANGE=1 (one all-gather per iteration) and =2 (direct: p replicas and mailboxes of the other
+    PROCESSES mapped through HIP IPC, no collective inside the iteration) under `mpiexec -n 4`, run to
+    convergence; set-up collectives go through the stream-ordered test double."""
+    import json
+    exe = os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP_RCCL_mpi.out")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(exe) and os.path.exists(mpiexec)):
+        pytest.skip("MPI driver not built (make mpi)")
+    env = {"LD_PRELOAD": mock_async, "GPU_MAX_HW_QUEUES": "8", "MOCK_RCCL_STATS_FILE": str(tmp_path / "st.jsonl"),
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LAM_HIP_EXCHANGE": exchange}
+    genv = []
+    for k, v in env.items():
+        genv += ["-genv", k, v]
+    sol = tmp_path / "sol.bin"
+    r = _run([mpiexec, "-n", "4"] + genv + [exe, "-s", "4096", "-o", str(sol)])
+    _skip_if_no_ipc(r)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = _csv(r.stdout)
+    assert f[0] == "4096" and f[1] == "4" and int(f[7]) == 2048 and float(f[8]) < 1e-9, f
+    x = np.fromfile(sol, dtype=np.float64, offset=16)
+    A_x = 2 * x; A_x[1:] += x[:-1]; A_x[:-1] += x[1:]
+    assert np.linalg.norm(A_x - 1.0) / np.sqrt(4096) < 1e-8
+    lines = [json.loads(l) for l in open(tmp_path / "st.jsonl")]
+    assert len(lines) == 4 and all(l["abort"] == 0 for l in lines) and len({l["calls"] for l in lines}) == 1, lines
+    if exchange == "2":
+        assert lines[0]["calls"] < 40        # set-up + solution gather only: nothing per iteration
+
+
 @pytest.mark.parametrize("exe_name", ["test_CG_MultiGPUS_HIP_RCCL.out", "test_CG_MultiGPUS_CUDA_NCCL.out"])
 def test_env_launched_driver_multi_rank(tmp_path, mock_mp_lib, golden, oracle, exe_name):
     """No MPI: P processes that only get RANK / WORLD_SIZE / LOCAL_RANK from their launcher (what
