@@ -27,16 +27,19 @@ def main():
     ap.add_argument("--tol", type=float, default=None)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--cond", type=float, default=200.0)
+    ap.add_argument("--dtype", choices=["f64", "f32", "bf16"], default="f64")
     ap.add_argument("--no-single", action="store_true", help="skip the single-shard comparison run")
     a = ap.parse_args()
     P, n, mode = a.P, a.n, a.mode
+    DT = {"f64": lam.F64, "f32": lam.F32, "bf16": lam.BF16}[a.dtype]
+    vdt = np.float64 if a.dtype == "f64" else np.float32
     tol = a.tol if a.tol is not None else (1e-9 if mode == "tridiag" else 1e-10)
     iters = a.iters if a.iters is not None else (10000 if mode == "tridiag" else 2000)
     uid = lam.get_unique_id()
     assert uid.startswith(b"/lam_mock_") or uid.startswith(b"mock-rccl-"), "the mock is not in front of librccl"
     out = [None] * P
     errs = []
-    xprobe = np.arange(n, dtype=np.float64) / n
+    xprobe = (np.arange(n, dtype=np.float64) / n).astype(vdt)
 
     def setup(s):
         if mode == "tridiag":
@@ -48,7 +51,7 @@ def main():
 
     def rank_main(r):
         try:
-            with lam.Solver(lam.F64, rank=r, nranks=P, device_id=0, unique_id=uid) as s:
+            with lam.Solver(DT, rank=r, nranks=P, device_id=0, unique_id=uid) as s:
                 setup(s)
                 s.set_option("overlap", a.overlap)
                 s.set_option("exchange", a.exchange)
@@ -91,7 +94,7 @@ def main():
     }
     if not a.no_single:
         # the same system on one shard, no RCCL
-        with lam.Solver(lam.F64) as s:
+        with lam.Solver(DT) as s:
             setup(s)
             s.solve(iters, tol)
             x1, it1 = s.solution(), s.stats["num_iters"]

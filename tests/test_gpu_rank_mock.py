@@ -152,6 +152,27 @@ def test_stop_protocol_keeps_ranks_in_step(mock_async, tmp_path, P, n, mode, exc
         _check_solution(out, P, n, mode)
 
 
+@pytest.mark.parametrize("P,n,mode,dtype,exchange", [
+    (4, 4096, "spd", "f32", 0), (4, 4096, "spd", "f32", 1), (4, 4096, "spd", "f32", 2),
+    (2, 2048, "tridiag", "bf16", 0), (3, 4104, "spd", "bf16", 2),
+])
+def test_rank_mode_low_precision(mock_async, tmp_path, P, n, mode, dtype, exchange):
+    """float vectors (and bf16 matrix storage) through every exchange: the vector element type changes the
+    all-gather datatype, the record layout of exchange 1 and the store width of the direct exchange."""
+    opts = ["--exchange", exchange, "--dtype", dtype, "--tol", 2e-5]
+    if mode == "tridiag":
+        opts += ["--iters", 40]            # fixed count: tridiag(1,2,1) needs N/2 iterations, too many for fp32 rounding
+    r, out, lines = _run(mock_async, tmp_path, P, n, mode, *opts)
+    _check_mock_stats(lines, P)
+    assert out["ranks_identical"] and len(set(out["collectives_enqueued"])) == 1, out
+    assert abs(out["iters"] - out["iters_single"]) <= 3, out
+    assert out["x_vs_single"] < 1e-3 and out["gemv_vs_single"] < 1e-5, out
+    if mode == "spd":
+        assert out["converged"] and out["true_residual"] < 1e-4, out
+    if exchange == 2:
+        assert out["exchange_effective"] == [2] * P
+
+
 def test_finalize_kernel_variant_matches_in_kernel_reduction(mock_async, tmp_path):
     """option finalize=0 (separate 1-block reduction launches, the round-1 chain) and the default in-kernel
     last-arriver reduction give bit-identical solves."""
