@@ -412,13 +412,49 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
                     for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
             }
         } else {
-            for (uint32_t c = lane * VEC; c < cols; c += STEP) {
+            // ragged last tile: whole wave steps with the streaming body, then the bounds-checked remainder
+            const int full = (int)(cols / STEP);
+            int sfull = 0;
+#pragma unroll 1
+            for (; sfull + UNROLL <= full; sfull += UNROLL) {
+                avec_t av[UNROLL][R];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const avec_t av = *reinterpret_cast<const avec_t *>(rowp[r] + c0 + c - (uint64_t)lane * VEC);
+                for (int u = 0; u < UNROLL; u++)
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av, i) * pt[c + i];
+                    for (int r = 0; r < R; r++) {
+                        const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * STEP);
+                        av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
+                    }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * pt[(sfull + u) * STEP + lane * VEC + i];
+            }
+            {   // fewer than UNROLL whole steps + a partial one: one predicated group, loads in flight together
+                avec_t av[UNROLL][R];
+                bool on[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const uint32_t c = (uint32_t)(sfull + u) * STEP + lane * VEC;
+                    on[u] = c < cols;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (on[u]) {
+                            const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * STEP);
+                            av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
+                        }
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++)
+                    if (on[u]) {
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+#pragma unroll
+                            for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * pt[(sfull + u) * STEP + lane * VEC + i];
+                    }
             }
         }
         tt = (tt + 1 == ntiles) ? 0 : tt + 1;
@@ -529,13 +565,52 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
                     for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
             }
         } else {
-            for (uint32_t c = woff; c < cols; c += STEP * WAVES) {
+            // ragged last tile of a segment (N not a multiple of TILE: 18 % of the columns at N=10000): the same
+            // streaming body over its whole super-steps, then one bounds-checked vector per lane
+            const int full = (int)(cols / (STEP * WAVES));
+            int sfull = 0;
+#pragma unroll 1
+            for (; sfull + UNROLL <= full; sfull += UNROLL) {
+                avec_t av[UNROLL][R];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const avec_t av = *reinterpret_cast<const avec_t *>(rowp[r] + c0 + c - woff);
+                for (int u = 0; u < UNROLL; u++)
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av, i) * s_p[c + i];
+                    for (int r = 0; r < R; r++) {
+                        const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * (STEP * WAVES));
+                        av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
+                    }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * s_p[(sfull + u) * (STEP * WAVES) + woff + i];
+            }
+            // what is left is fewer than UNROLL whole super-steps plus a partial one: one predicated group,
+            // all of its loads in flight together (a step-at-a-time loop here is a chain of HBM latencies)
+            {
+                avec_t av[UNROLL][R];
+                bool on[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const uint32_t c = (uint32_t)(sfull + u) * (STEP * WAVES) + woff;
+                    on[u] = c < cols;                  // cols and woff are multiples of VEC: all of the vector or none
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (on[u]) {
+                            const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * (STEP * WAVES));
+                            av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
+                        }
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++)
+                    if (on[u]) {
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+#pragma unroll
+                            for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * s_p[(sfull + u) * (STEP * WAVES) + woff + i];
+                    }
             }
         }
         tt = (tt + 1 == ntiles) ? 0 : tt + 1;
