@@ -231,37 +231,57 @@ def main():
                     (base + "RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration on one stream (no overlap)",))
         runs.append(timed("allgather_Ap", exchange=1, overlap=1) +
                     (base + "ONE RCCL all-gather of [Ap slice | p.Ap partial] per iteration (full-length r, p per rank)",))
-        # Last, because a failure here leaves the ranks out of step: the direct exchange (peer-mapped
-        # mailboxes, no collective call inside the iteration).  A rank that cannot map its peers falls back to
-        # exchange 0 (all ranks agree); a bounded wait that expires raises -- then nothing collective follows.
-        try:
-            if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
-                raise RuntimeError("skipped (LAM_BENCH_DIRECT=0)")
-            s.set_option("exchange", 2)
-            s.set_option("overlap", 1)
-            s.cg_init()
-            if s.get_option("exchange_effective") != 2:
-                raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
-            if args.warmup > 0:
-                s.cg_iterate(args.warmup, 0.0)
-            barrier()
-            t0_ = time.perf_counter()
-            st_ = s.cg_iterate(args.steps, 0.0)
-            barrier()
-            dt_, st_ = max_over_ranks(time.perf_counter() - t0_, st_)
-            res_ = s.true_residual()
-            exchange_modes["direct_mailboxes"] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
-                                                  "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_,
-                                                  "rel_residual_recursive": st_["rel_err"]}
-            # a candidate for the headline only if it solved the same problem: all exchanges are deterministic
-            # and agree to rounding, and the recomputed residual must match the recursive one
-            if abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / runs[0][2] - 1) < 1e-6:
-                runs.append((dt_, st_, res_, base + "direct stores into peer-mapped mailboxes and p replicas over xGMI "
-                                                    "(no collective call inside the iteration)"))
+        # Last, because a failure here leaves the ranks' device state out of step: the direct exchange (peer-
+        # mapped mailboxes, no collective call inside the iteration).  Every step ends with an agreement over the
+        # control plane, so all ranks take the same path: a rank that cannot map its peers (all ranks then fall back
+        # to exchange 0) or a bounded wait that expires ends the attempt on ALL ranks, and nothing collective on the
+        # device follows it.
+        def agree(ok_):
+            return all(x == b"1" for x in rdzv.allgather(b"1" if ok_ else b"0"))
+
+        def attempt(fn):
+            try:
+                return True, fn(), None
+            except Exception as e:   # noqa: BLE001
+                return False, None, str(e)[:300]
+
+        direct = {}
+        if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
+            direct["error"] = "skipped (LAM_BENCH_DIRECT=0)"
+        else:
+            def init_direct():
+                s.set_option("exchange", 2)
+                s.set_option("overlap", 1)
+                s.cg_init()
+                if s.get_option("exchange_effective") != 2:
+                    raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
+            ok_, _, err_ = attempt(init_direct)
+            if not agree(ok_):
+                direct["error"] = err_ or "another rank could not set up the direct exchange"
             else:
-                exchange_modes["direct_mailboxes"]["error"] = "residual differs from the RCCL exchanges: not used as the headline"
-        except Exception as e:   # noqa: BLE001
-            exchange_modes["direct_mailboxes"] = {"error": str(e)[:300]}
+                ok_, _, err_ = attempt(lambda: s.cg_iterate(args.warmup, 0.0) if args.warmup > 0 else None)
+                if not agree(ok_):                      # doubles as the barrier in front of the timed region
+                    direct["error"] = err_ or "another rank failed in the warm-up"
+                else:
+                    t0_ = time.perf_counter()
+                    ok_, st_, err_ = attempt(lambda: s.cg_iterate(args.steps, 0.0))
+                    all_ok_ = agree(ok_)                # doubles as the closing barrier
+                    dt_ = time.perf_counter() - t0_
+                    if not all_ok_:
+                        direct["error"] = err_ or "another rank failed in the timed iterations"
+                    else:
+                        dt_, st_ = max_over_ranks(dt_, st_)
+                        res_ = s.true_residual()
+                        direct = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
+                                  "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
+                        # a candidate for the headline only if it solved the same problem: all exchanges are
+                        # deterministic and agree to rounding, and the recomputed residual must match the recursive one
+                        if abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / runs[0][2] - 1) < 1e-6:
+                            runs.append((dt_, st_, res_, base + "direct stores into peer-mapped mailboxes and p replicas over "
+                                                                "xGMI (no collective call inside the iteration)"))
+                        else:
+                            direct["error"] = "residual differs from the RCCL exchanges: not used as the headline"
+        exchange_modes["direct_mailboxes"] = direct
         dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])
     n_coll = s.get_option("collectives_enqueued")
 
