@@ -739,6 +739,8 @@ int setup_direct(lam_hip_ctx *c)
     ShardBase &s = c->sh[0];
     LAMCHK(set_dev(c, s));
     bool ok = true;
+    if (const char *off = getenv("LAM_HIP_DIRECT_DISABLE"))        // pretend this rank cannot map its peers: every rank
+        if (*off && strcmp(off, "0") != 0) ok = false;            // must then fall back together (tests; a kill switch)
     if (c->mail == nullptr) {
         // fine-grained memory: polled by this rank's kernels while peers write it over xGMI
         if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocUncached) != hipSuccess) {
@@ -863,6 +865,11 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         MailPost post = no_post();
         post.n = P; post.rank = c->rank; post.seq = seq;
         for (int q = 0; q < P; q++) post.mail[q] = c->peer_mail[q];
+        // LAM_HIP_DEBUG_DIRECT_DROP=<rank>: test hook -- that rank "forgets" to raise its p-slice flags in iteration
+        // 3, so every bounded wait downstream of it expires: shows that the grid drains, the error surfaces on all
+        // ranks and the caller survives (tests/test_gpu_rank_mock.py).  Never set it otherwise.
+        static const char *drop = getenv("LAM_HIP_DEBUG_DIRECT_DROP");
+        if (drop && *drop && atoi(drop) == c->rank && k == 3) post.seq = ~0ull;
         hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
                            rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows, (volatile int *)s.host_flags,
                            MailWait{c->mail->rr, P, seq, c->direct_err}, post);
