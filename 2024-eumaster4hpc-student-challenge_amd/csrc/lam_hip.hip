@@ -549,6 +549,10 @@ int sync_all(lam_hip_ctx *c)
     return 0;
 }
 
+// Does the producer launch of this dot product carry a reducer workgroup (lam_kernels.h, Finalize)?  The
+// symmetric product's second pass writes plain per-workgroup partials of p.Ap: its consumer sums them.
+bool producer_reduces(const lam_hip_ctx *c, bool second) { return c->opt_finalize != 0 && (second || !c->symv_active()); }
+
 // Where the reduced partial of shard `s` goes (see lam_kernels.h, Finalize): slot `index` of the
 // gather array of every local shard (one process: peer stores) or of this rank (rank mode).
 Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
@@ -559,13 +563,14 @@ Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
     f.seq = 0;
     f.dst.n = 0;
     f.slot = s.index;
-    if (!c->rank_mode && c->total_shards == 1) return f;
     if (c->rank_mode) { f.dst.n = 1; f.dst.p[0] = second ? s.gather_b : s.gather_a; }
     else {
+        // one process: slot q of every local shard's gather array (one shard: its own array, slot 0 -- the
+        // consumer then reads ONE number instead of summing 32768 GEMV partials in each of its workgroups)
         f.dst.n = (int)c->sh.size();
         for (int j = 0; j < f.dst.n; j++) f.dst.p[j] = second ? (void *)c->sh[j].gather_b : (void *)c->sh[j].gather_a;
     }
-    f.active = c->opt_finalize ? 1 : 0;
+    f.active = producer_reduces(c, second) ? 1 : 0;
     return f;
 }
 
@@ -609,9 +614,9 @@ int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop
     return 0;
 }
 
-void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, const double **red, int *nred)
+void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, bool finalized, const double **red, int *nred)
 {
-    if (!c->rank_mode && c->total_shards == 1) {
+    if (!c->rank_mode && c->total_shards == 1 && !finalized) {
         *red = use_gemv_part ? s.part_gemv : s.part_vec;
         *nred = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
     } else {
@@ -692,7 +697,7 @@ template <typename TA_, typename TV_> struct ImplTraits<Impl<TA_, TV_>> { using 
 // a roofline probe) is behind it in stream order.
 int arm_partials(lam_hip_ctx *c)
 {
-    if ((!c->rank_mode && c->total_shards == 1) || !c->opt_finalize) return 0;
+    if (!c->opt_finalize) return 0;
     for (auto &s : c->sh) {
         LAMCHK(set_dev(c, s));
         hipLaunchKernelGGL(arm_partials_kernel, dim3(std::max(1, std::min(64, s.part_gemv_cap / kBlock))), dim3(kBlock), 0, s.stream,
@@ -966,7 +971,7 @@ int do_cg_init(lam_hip_ctx *c)
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             const double *red; int nred;
-            red_source(c, s, true, false, &red, &nred);
+            red_source(c, s, true, false, /*finalized=*/false, &red, &nred);
             hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(kBlock), 0, s.stream, red, nred, s.sc);
             HIPCHK(c, hipGetLastError());
         }
@@ -1017,26 +1022,26 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             }
         }
         c->gather_pending = false;
-        const bool fin = c->opt_finalize != 0;
-        LAMCHK(reduce_step(c, false, true, true, fin));
+        const bool fin_a = producer_reduces(c, false), fin_b = producer_reduces(c, true);
+        LAMCHK(reduce_step(c, false, true, true, fin_a));
         // 2. x, r update + partial r.r
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             const double *red; int nred;
-            red_source(c, s, false, true, &red, &nred);
+            red_source(c, s, false, true, fin_a, &red, &nred);
             const Finalize fb = make_finalize(c, s, true);
             hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + (fb.active ? 1 : 0)), dim3(kBlock), 0, s.stream, red, nred,
                                s.sc, k, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
                                MailWait{nullptr, 0, 0, nullptr});
             HIPCHK(c, hipGetLastError());
         }
-        LAMCHK(reduce_step(c, true, false, true, fin));
+        LAMCHK(reduce_step(c, true, false, true, fin_b));
         // 3. stop test + p update (into every replica)
         PtrList pl = plist_p(c);
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             const double *red; int nred;
-            red_source(c, s, true, false, &red, &nred);
+            red_source(c, s, true, false, fin_b, &red, &nred);
             hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
                                rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows,
                                (volatile int *)s.host_flags, MailWait{nullptr, 0, 0, nullptr}, no_post());
