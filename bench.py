@@ -21,7 +21,9 @@ second ROCm runtime and a second RCCL) and the data path is RCCL inside liblam_h
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (its name comes from the
 library): achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
-the launch stream inside the timed steps.  `cpu_baseline` (rank 0, N=1 only) times the reference's
+the launch stream inside the timed steps; `roofline.traffic` = HBM bytes per launch from two short rocprofv3
+PMC passes run as child processes at the start (N=1; otherwise the committed profile's value, tagged).
+`cpu_baseline` (rank 0, N=1 only) times the reference's
 own CPU driver (oracle/_ref, built from /root/reference in the build container) -- or, if that
 binary is missing, the oracle port -- on a bounded sample.
 """
@@ -113,6 +115,47 @@ def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=Fals
     return st, dt
 
 
+def measure_traffic(n):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two short rocprofv3 PMC passes over this very
+    script (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes; bytes = (2*FETCH_SIZE
+    + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE counts a 128-B request as 64 B), run as child processes before this
+    process touches the GPU.  Returns (bytes, source-dict) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals, kernel = {}, None
+    work = tempfile.mkdtemp(prefix="lam_pmc_")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, ctr)
+            cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--order", str(n), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-also",
+                   "--no-traffic"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=work, env=dict(os.environ, TMPDIR=work))
+            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            rows = [x for x in csv.DictReader(open(files[0])) if "gemv_" in x["Kernel_Name"] and x["Counter_Name"] == ctr]
+            if not rows:
+                return None, f"no GEMV launch in the {ctr} pass"
+            grid = max(int(x["Grid_Size"]) for x in rows)
+            sel = [float(x["Counter_Value"]) for x in rows if int(x["Grid_Size"]) == grid]
+            vals[ctr] = sum(sel) / len(sel)
+            kernel = next(x["Kernel_Name"] for x in rows if int(x["Grid_Size"]) == grid)
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, {
+            "measured_in_this_run": True, "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 5 steps each) "
+                                                 "on this script as child processes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+            "FETCH_SIZE_KiB": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "kernel": kernel}
+    except Exception as e:   # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def traffic_record(n, n_gpus):
     """HBM bytes per launch of the dominant kernel from the PMC counters.  They cannot be collected inside
     an un-profiled run, so this is the value of the committed rocprofv3 passes (profiles/traffic.json), tagged
@@ -138,6 +181,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the extra sizes and the symmetric-option run")
     ap.add_argument("--symmetric", action="store_true",
                     help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes (roofline.traffic then "
+                    "comes from profiles/traffic.json, tagged as such)")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     args = ap.parse_args()
@@ -163,6 +208,11 @@ def main():
     cb = None
     if solo and not args.no_cpu_baseline and not profiled:
         cb = cpu_baseline(args.cpu_sample_n, args.cpu_sample_iters)
+    live_traffic = (None, None)
+    if solo and not args.no_traffic and not profiled and not args.symmetric:
+        live_traffic = measure_traffic(args.n)
+        if live_traffic[0] is None:
+            sys.stderr.write(f"[bench] live PMC traffic measurement not available: {live_traffic[1]}\n")
 
     if use_dist:
         uid = rdzv.broadcast(lam.get_unique_id() if rank == 0 else b"")
@@ -314,7 +364,12 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     gemv_bytes = st["gemv_bytes"]                 # algorithmic bytes of ONE launch on one GPU
     achieved = gemv_bytes / st["t_gemv"] / 1e9 if st["t_gemv"] > 0 else 0.0
-    traffic, traffic_src = traffic_record(n, n_gpus)
+    if live_traffic[0] is not None:
+        traffic, traffic_src = live_traffic
+    else:
+        traffic, traffic_src = traffic_record(n, n_gpus)
+        if traffic_src is not None and live_traffic[1]:
+            traffic_src["live_measurement"] = live_traffic[1]
 
     out = {
         "metric": "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
