@@ -575,8 +575,9 @@ Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
 }
 
 // Exchange the shards' partials of a dot product so that the next kernel can sum them in shard order.
-//   1 shard            : nothing (the consumer sums the workgroup partials)
-//   several, 1 process : the producer's last workgroup stored the shard's partial into slot q of every
+//   1 shard            : nothing (the producer's reducer workgroup left the total in gather[0]; without a
+//                        reducer -- option finalize = 0, the symmetric product -- the consumer sums the partials)
+//   several, 1 process : the producer's reducer workgroup stored the shard's partial into slot q of every
 //                        shard's gather array (peer stores); events order the consumers behind them
 //   rank mode          : in-place ncclAllGather of the 8-byte partials (slot = rank)
 // `finalized` = the producer kernel already reduced its partials (Finalize); otherwise a 1-block
