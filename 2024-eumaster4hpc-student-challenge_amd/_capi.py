@@ -78,6 +78,7 @@ def lib():
             "lam_hip_generate_tridiag": ([vp], i32),
             "lam_hip_generate_random_spd": ([vp, u64, C.c_double], i32),
             "lam_hip_set_rhs": ([vp, vp], i32),
+            "lam_hip_get_rhs": ([vp, vp], i32),
             "lam_hip_generate_rhs": ([vp, C.c_double], i32),
             "lam_hip_generate_random_rhs": ([vp, u64], i32),
             "lam_hip_solve": ([vp, i32, C.c_double, C.POINTER(Stats)], i32),
@@ -256,6 +257,11 @@ class Solver:
         b = np.ascontiguousarray(b, dtype=self.vec_dtype).reshape(-1)
         assert b.size == self.n
         self._chk(self._L.lam_hip_set_rhs(self._h, b.ctypes.data_as(C.c_void_p)))
+
+    def rhs(self):
+        b = np.empty(self.n, dtype=self.vec_dtype)
+        self._chk(self._L.lam_hip_get_rhs(self._h, b.ctypes.data_as(C.c_void_p)))
+        return b
 
     # -- file mode (format: random_spd_system.cpp:105-121) ------------------------------------------
     def load_matrix_from_file(self, filename, chunk_bytes=256 << 20):

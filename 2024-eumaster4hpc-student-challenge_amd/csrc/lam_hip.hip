@@ -1395,6 +1395,20 @@ int lam_hip_set_rhs(lam_hip_ctx *c, const void *b_host)
     return 0;
 }
 
+int lam_hip_get_rhs(lam_hip_ctx *c, void *b_host)
+{
+    if (!c || !b_host) return LAM_HIP_EINVAL;
+    if (!c->have_rhs) return fail(c, LAM_HIP_ESTATE, "rhs not set");
+    if (c->rank_mode) return fail(c, LAM_HIP_EINVAL, "lam_hip_get_rhs is for single-process contexts");
+    const size_t ev = c->esz_v();
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        HIPCHK(c, hipMemcpyAsync((char *)b_host + s.row0 * ev, s.b, s.nrows * ev, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+    }
+    return 0;
+}
+
 static int gen_rhs(lam_hip_ctx *c, int random, uint64_t seed, double value)
 {
     if (!c) return LAM_HIP_EINVAL;

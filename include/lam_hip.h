@@ -130,6 +130,10 @@ int lam_hip_generate_random_spd(lam_hip_ctx *ctx, uint64_t seed, double cond);
 /* b: load_rhs_from_file (ConjugateGradient_CPU_MPI_OMP.hpp:258-305) / generate_rhs (:144-165).
  * b_host has N elements of the vector dtype (double for F64, float otherwise). */
 int lam_hip_set_rhs(lam_hip_ctx *ctx, const void *b_host);
+/* b back to the host (N elements of the vector dtype; single-process contexts): lets a generated system be
+ * written to files in the reference's format (apps/random_spd_system.cpp, the counterpart of
+ * challenge/main/random_spd_system.cpp:160-185). */
+int lam_hip_get_rhs(lam_hip_ctx *ctx, void *b_host);
 int lam_hip_generate_rhs(lam_hip_ctx *ctx, double value);          /* b == value (reference: 1.0) */
 int lam_hip_generate_random_rhs(lam_hip_ctx *ctx, uint64_t seed);  /* b ~ U[-1,1) */
 

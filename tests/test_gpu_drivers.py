@@ -347,3 +347,27 @@ def test_file_mode_past_2_31_elements(lam, tmp_path):
         print(f"17.2 GB file: load + solve + save with test_CG_single_GPU.out took {t_one:.1f} s")
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_generator_tool_with_the_reference_cli(tmp_path, oracle):
+    """apps/random_spd_system.out: the reference generator's command line (`size matrix rhs seed`,
+    challenge/main/random_spd_system.cpp:127-196), its prints and exit codes; the system is generated on the
+    device and written in the reference's format.  The files must be a symmetric positive definite system that the
+    positional driver solves and that the CPU oracle solves to the same solution."""
+    gen = os.path.join(ROOT, "2024-eumaster4hpc-student-challenge_amd", "apps", "random_spd_system.out")
+    mat, rhs, sol = (str(tmp_path / f) for f in ("matrix.bin", "rhs.bin", "sol.bin"))
+    r = _run([gen, "300", mat, rhs, "42"])
+    assert r.returncode == 0 and "Finished successfully" in r.stdout, r.stdout + r.stderr
+    assert _run([gen, "0", mat, rhs, "1"]).returncode == 1                       # "Wrong argument value"
+    assert _run([gen, "16", str(tmp_path / "no" / "dir.bin"), rhs, "1"]).returncode == 2
+    A = oracle.read_bin(mat)
+    b = oracle.read_bin(rhs).reshape(-1)
+    assert A.shape == (300, 300) and b.shape == (300,)
+    assert np.array_equal(A, A.T) and np.linalg.eigvalsh(A).min() > 0
+    r2 = _run([gen, "300", str(tmp_path / "m2.bin"), str(tmp_path / "r2.bin"), "42"])   # seeded: reproducible
+    assert r2.returncode == 0 and open(mat, "rb").read() == open(tmp_path / "m2.bin", "rb").read()
+    r = _run([ONE_EXE, mat, rhs, sol, "2000", "1e-10"])
+    assert r.returncode == 0 and "Converged in" in r.stdout, r.stdout + r.stderr
+    x = oracle.read_bin(sol).reshape(-1)
+    x_ref, st = oracle.cg_solve(A, b, 2000, 1e-10)
+    assert st["converged"] and np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-7
