@@ -84,6 +84,11 @@ class Rendezvous:
             srv.settimeout(1.0)
             while len(peers) < self.size - 1:
                 if time.time() > deadline:
+                    srv.close()
+                    for c in peers.values():
+                        c.close()
+                    os.unlink(path)           # do not leave a file behind that nobody listens to
+                    self._file = None
                     raise TimeoutError(f"rendezvous: only {len(peers) + 1} of {self.size} ranks arrived")
                 try:
                     conn, _ = srv.accept()

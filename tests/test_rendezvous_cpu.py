@@ -70,3 +70,20 @@ def test_single_process_needs_no_rendezvous(lam):
         r.barrier(); r.close()
     finally:
         os.environ.update(env_backup)
+
+
+def test_rendezvous_times_out_when_a_rank_never_arrives(tmp_path):
+    """A launch that loses a rank must fail with an error, not wait for ever: rank 0 of a 2-rank world whose
+    peer never starts gives up after the timeout and removes its rendezvous file."""
+    path = str(tmp_path / "rdzv")
+    code = ("import importlib, sys; sys.path.insert(0, %r); lam = importlib.import_module(%r)\n"
+            "try:\n    lam.Rendezvous(timeout=2.0); print('CONNECTED')\n"
+            "except TimeoutError as e:\n    print('TIMEOUT', e)\n" % (ROOT, PKG_NAME))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMI_RANK", "PMI_SIZE")}
+    env.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", LAM_RDZV_FILE=path)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert "TIMEOUT" in r.stdout and "1 of 2" in r.stdout, r.stdout + r.stderr
+    assert not os.path.exists(path)
+    env.update(RANK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
+    assert "TIMEOUT" in r.stdout, r.stdout + r.stderr
