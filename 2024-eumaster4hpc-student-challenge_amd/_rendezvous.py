@@ -1,6 +1,6 @@
 """Launcher glue for one-process-per-GPU runs from Python (bench.py, tests): who am I, and a tiny
 control plane (broadcast of the 128-byte RCCL unique id, barrier, max over ranks).  Python twin of
-test/lam_bootstrap.hpp; the reference does the same job with MPI_Comm_rank/size + MPI_Bcast
+LAM/src/HIP/lam_bootstrap.hpp; the reference does the same job with MPI_Comm_rank/size + MPI_Bcast
 (/root/reference/challenge/main/LAM/src/GPU/distributed/ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:320-327).
 
 Deliberately NOT torch.distributed: torch ships its own copies of the ROCm runtime and of RCCL under

@@ -1,5 +1,5 @@
 """The torch-free control plane bench.py uses under a launcher (package _rendezvous.py; Python twin of
-test/lam_bootstrap.hpp): world_size 2 and 3 as real processes on CPU.  Pins rank/size discovery from
+LAM/src/HIP/lam_bootstrap.hpp): world_size 2 and 3 as real processes on CPU.  Pins rank/size discovery from
 the launcher's environment, the unique-id broadcast, barrier, max-over-ranks, that a stale rendezvous
 file of a dead launch is not mistaken for the live one, and that no rank process imports torch."""
 import json
