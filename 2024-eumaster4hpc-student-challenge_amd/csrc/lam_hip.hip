@@ -826,7 +826,9 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         //    behind the own-slice panel.
         uint64_t lo = 0, hi = 0;
         uint64_t a = s.row0, b = s.row0 + s.nrows;
-        if (P > 1 && (!I::fast_ok(c) || (a % I::VEC == 0 && b % I::VEC == 0))) { lo = a; hi = b; }
+        // option "overlap" = 0: no own-slice panel -- wait for the flags first, then one GEMV launch (the split
+        // costs ~8 us of launch and ramp; it pays when the slices arrive later than that)
+        if (P > 1 && c->opt_overlap && (!I::fast_ok(c) || (a % I::VEC == 0 && b % I::VEC == 0))) { lo = a; hi = b; }
         Finalize fa;
         fa.active = 1; fa.mail = 1; fa.seq = seq; fa.slot = 0; fa.dst.n = P;
         for (int q = 0; q < P; q++) fa.dst.p[q] = &c->peer_mail[q]->pap[c->rank];

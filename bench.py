@@ -295,43 +295,49 @@ def main():
             except Exception as e:   # noqa: BLE001
                 return False, None, str(e)[:300]
 
-        direct = {}
-        if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
-            direct["error"] = "skipped (LAM_BENCH_DIRECT=0)"
-        else:
-            def init_direct():
-                s.set_option("exchange", 2)
-                s.set_option("overlap", 1)
-                s.cg_init()
-                if s.get_option("exchange_effective") != 2:
-                    raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
-            ok_, _, err_ = attempt(init_direct)
+        def init_direct(overlap):
+            s.set_option("exchange", 2)
+            s.set_option("overlap", overlap)
+            s.cg_init()
+            if s.get_option("exchange_effective") != 2:
+                raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
+
+        def try_direct(label, overlap, what):
+            """One timed run on the direct exchange; records it under `label`; True if it produced a number."""
+            if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
+                exchange_modes[label] = {"error": "skipped (LAM_BENCH_DIRECT=0)"}
+                return False
+            ok_, _, err_ = attempt(lambda: init_direct(overlap))
             if not agree(ok_):
-                direct["error"] = err_ or "another rank could not set up the direct exchange"
+                exchange_modes[label] = {"error": err_ or "another rank could not set up the direct exchange"}
+                return False
+            ok_, _, err_ = attempt(lambda: s.cg_iterate(args.warmup, 0.0) if args.warmup > 0 else None)
+            if not agree(ok_):                          # doubles as the barrier in front of the timed region
+                exchange_modes[label] = {"error": err_ or "another rank failed in the warm-up"}
+                return False
+            t0_ = time.perf_counter()
+            ok_, st_, err_ = attempt(lambda: s.cg_iterate(args.steps, 0.0))
+            all_ok_ = agree(ok_)                        # doubles as the closing barrier
+            dt_ = time.perf_counter() - t0_
+            if not all_ok_:
+                exchange_modes[label] = {"error": err_ or "another rank failed in the timed iterations"}
+                return False
+            dt_, st_ = max_over_ranks(dt_, st_)
+            res_ = s.true_residual()
+            exchange_modes[label] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
+                                     "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
+            # a candidate for the headline only if it solved the same problem: all exchanges are deterministic and
+            # agree to rounding, and the recomputed residual must match the recursive one
+            if abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / runs[0][2] - 1) < 1e-6:
+                runs.append((dt_, st_, res_, base + what))
             else:
-                ok_, _, err_ = attempt(lambda: s.cg_iterate(args.warmup, 0.0) if args.warmup > 0 else None)
-                if not agree(ok_):                      # doubles as the barrier in front of the timed region
-                    direct["error"] = err_ or "another rank failed in the warm-up"
-                else:
-                    t0_ = time.perf_counter()
-                    ok_, st_, err_ = attempt(lambda: s.cg_iterate(args.steps, 0.0))
-                    all_ok_ = agree(ok_)                # doubles as the closing barrier
-                    dt_ = time.perf_counter() - t0_
-                    if not all_ok_:
-                        direct["error"] = err_ or "another rank failed in the timed iterations"
-                    else:
-                        dt_, st_ = max_over_ranks(dt_, st_)
-                        res_ = s.true_residual()
-                        direct = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
-                                  "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
-                        # a candidate for the headline only if it solved the same problem: all exchanges are
-                        # deterministic and agree to rounding, and the recomputed residual must match the recursive one
-                        if abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / runs[0][2] - 1) < 1e-6:
-                            runs.append((dt_, st_, res_, base + "direct stores into peer-mapped mailboxes and p replicas over "
-                                                                "xGMI (no collective call inside the iteration)"))
-                        else:
-                            direct["error"] = "residual differs from the RCCL exchanges: not used as the headline"
-        exchange_modes["direct_mailboxes"] = direct
+                exchange_modes[label]["error"] = "residual differs from the RCCL exchanges: not used as the headline"
+            return True
+
+        if try_direct("direct_mailboxes", 1, "direct stores into peer-mapped mailboxes and p replicas over xGMI (no collective call "
+                                             "inside the iteration); own-slice GEMV panel runs while the slices arrive"):
+            try_direct("direct_mailboxes, no split", 0, "direct stores into peer-mapped mailboxes and p replicas over xGMI (no collective "
+                                                        "call inside the iteration); one GEMV launch behind the flag wait")
         dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])
     n_coll = s.get_option("collectives_enqueued")
 

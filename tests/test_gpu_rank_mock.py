@@ -85,6 +85,8 @@ def _check_solution(out, P, n, mode):
     (8, 8192, "spd", 1, 2),
     (3, 1001, "tridiag", 1, 2),     # odd N (generic kernel), uneven split
     (4, 4102, "spd", 1, 2),         # odd row offsets: the GEMV is not split
+    (4, 4096, "spd", 0, 2),         # overlap 0: flag wait first, then ONE GEMV launch
+    (8, 8192, "spd", 0, 2),
 ])
 def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, overlap, exchange):
     r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--overlap", overlap, "--exchange", exchange)
@@ -222,7 +224,7 @@ def _check_bench_line(r, nproc):
     assert out["n_gpus"] == nproc and out["steps"] == 20 and out["scaling"] == "strong" and out["dtype"] == "f64"
     assert out["metric"] == "cg_iterations_per_sec" and out["value"] > 0
     assert set(out["exchange_modes"]) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap",
-                                          "direct_mailboxes"}
+                                          "direct_mailboxes", "direct_mailboxes, no split"}
     for m in out["exchange_modes"].values():
         assert m.get("value", 0) > 0, out["exchange_modes"]
     # both exchanges solved the same problem: true residuals agree (different rounding only)
