@@ -220,7 +220,9 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   with the DMA); 0 (default) = hand the caller's pages to the runtime directly.
  *   "collectives_enqueued" (get only) RCCL calls this context has enqueued so far -- equal on all ranks.
  *   "overlap"       rank mode, exchange 0: 1 (default) puts the all-gather of p on a second stream under the
- *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.
+ *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.  Exchange 2: 1 runs
+ *                   that own-columns panel in front of the wait for the peers' p slices; 0 waits first and
+ *                   launches the GEMV once.
  *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype; 0..22 = tuning shapes
  *                   (tools/gemv_probe.py; 19-22 are the MFMA experiment, LAM_HIP_BF16 only).
  *   "nt_loads"      1 (default) = non-temporal loads for the matrix stream.
