@@ -109,6 +109,8 @@ struct lam_hip_ctx {
     bool gather_pending = false;   // an all-gather of p is in flight on comm_stream
     int64_t opt_symmetric = 0;     // single shard: read only the upper triangle (caller asserts A == A^T)
     int64_t opt_exchange = 0;      // rank mode: 0 = all-gather x2 (8 B/rank) + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
+    int64_t opt_fuse = 1;          // one shard / direct exchange: x, r and p updates in ONE launch (update_fused_kernel)
+    int waited_k = 0;              // direct exchange: the iteration whose fused launch already waited for the peers' p slices
     int64_t opt_reuse_matrix = 1;  // lam_hip_set_problem keeps (and re-uses) the matrix allocation when it is large enough
     int64_t opt_upload_staging = 0; // lam_hip_upload_rows: 1 = pipeline through two pinned staging buffers
     int64_t opt_finalize = 1;      // several shards: 1 = producer kernels reduce their partials themselves (Finalize);
@@ -116,6 +118,7 @@ struct lam_hip_ctx {
     uint64_t n_collectives = 0;    // RCCL calls enqueued by this context (diagnostics: must match across ranks)
     // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
     Mail *mail = nullptr;                       // own mailbox, fine-grained device memory
+    bool mail_coarse = false;                   // ... or ordinary device memory (enough for one shard, not for peers)
     Mail *peer_mail[kMaxShards] = {};           // every rank's mailbox as seen from here (own included)
     void *peer_p[kMaxShards] = {};              // every rank's p replica as seen from here (own included)
     void *ipc_opened[2 * kMaxShards] = {};      // mappings to close again
@@ -718,6 +721,32 @@ MailPost no_post()
     return p;
 }
 
+// The context's mailbox (lam_kernels.h, Mail) and the pinned error word of the bounded waits.  Fine-grained
+// (uncached) memory where the runtime offers it: in the direct exchange it is polled by this rank's kernels
+// while peers write it over xGMI; with one shard only the launch's own reducer workgroup writes it.
+int ensure_mail(lam_hip_ctx *c, bool *got_finegrained)
+{
+    if (got_finegrained) *got_finegrained = true;
+    if (c->mail == nullptr) {
+        if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                c->mail = nullptr;
+                c->mail_coarse = true;
+                HIPCHK(c, hipMalloc((void **)&c->mail, sizeof(Mail)));
+            }
+        }
+        HIPCHK(c, hipMemset(c->mail, 0, sizeof(Mail)));
+    }
+    if (got_finegrained) *got_finegrained = !c->mail_coarse;
+    if (c->direct_err == nullptr) {
+        HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));
+        memset(c->direct_err, 0, 64);
+    }
+    return 0;
+}
+
 // ---- direct exchange (option exchange = 2) --------------------------------------------------------
 void close_direct(lam_hip_ctx *c)
 {
@@ -747,17 +776,10 @@ int setup_direct(lam_hip_ctx *c)
     bool ok = true;
     if (const char *off = getenv("LAM_HIP_DIRECT_DISABLE"))        // pretend this rank cannot map its peers: every rank
         if (*off && strcmp(off, "0") != 0) ok = false;            // must then fall back together (tests; a kill switch)
-    if (c->mail == nullptr) {
-        // fine-grained memory: polled by this rank's kernels while peers write it over xGMI
-        if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocUncached) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); c->mail = nullptr; ok = false; }
-        }
-        if (c->mail) HIPCHK(c, hipMemset(c->mail, 0, sizeof(Mail)));
-        if (c->direct_err == nullptr) {
-            HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));
-            memset(c->direct_err, 0, 64);
-        }
+    {
+        bool fine = false;
+        LAMCHK(ensure_mail(c, &fine));
+        if (!fine) ok = false;                  // peers must not poll-and-write ordinary (cached) memory
     }
     const int P = c->nranks;
     constexpr size_t kRec = 256;
@@ -838,7 +860,8 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
             if (q < P) partition(c->n, P, q, &r0, &nr);
             nb.n[q] = q < P ? vec_grid(nr) : 0;
         }
-        const bool need_wait = P > 1 && k > 1;
+        // the fused update launch of iteration k-1 may have waited for the slices already (its waiter workgroup)
+        const bool need_wait = P > 1 && k > 1 && c->waited_k != k - 1;
         s.split_slot[slot] = hi > lo;
         if (hi > lo) {
             HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
@@ -862,6 +885,27 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         // 2. x, r: waits in the kernel for the P partials of p.Ap; its reducer posts the r.r partial
         Finalize fb = fa;
         for (int q = 0; q < P; q++) fb.dst.p[q] = &c->peer_mail[q]->rr[c->rank];
+        if (c->opt_fuse) {
+            // steps 2 and 3 in ONE launch; without an own-slice panel (overlap 0) a waiter workgroup also holds the
+            // launch open until the peers' slices for the next GEMV are in: 2 launches per iteration
+            PtrList plf;
+            plf.n = P;
+            for (int q = 0; q < P; q++) plf.p[q] = c->peer_p[q];
+            MailPost postf = no_post();
+            postf.n = P; postf.rank = c->rank; postf.seq = seq;
+            for (int q = 0; q < P; q++) postf.mail[q] = c->peer_mail[q];
+            static const char *dropf = getenv("LAM_HIP_DEBUG_DIRECT_DROP");
+            if (dropf && *dropf && atoi(dropf) == c->rank && k == 3) postf.seq = ~0ull;      // test hook, see below
+            const bool waiter = P > 1 && !(hi > lo);
+            hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1 + (waiter ? 1 : 0)), dim3(kBlock), 0, s.stream,
+                               (const double *)nullptr, 0, s.sc, k, rel_error, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x,
+                               (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fb, MailWait{c->mail->pap, P, seq, c->direct_err},
+                               MailWait{c->mail->rr, P, seq, c->direct_err}, plf, s.row0, (volatile int *)s.host_flags, postf,
+                               (const Mail *)c->mail, nb);
+            HIPCHK(c, hipGetLastError());
+            if (waiter) c->waited_k = k;
+            return 0;
+        }
         hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
                            (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
                            MailWait{c->mail->pap, P, seq, c->direct_err});
@@ -952,13 +996,15 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
 int do_cg_init(lam_hip_ctx *c)
 {
     c->cg_direct = false;
+    c->epoch++;                    // mailbox tags = (epoch << 32) | iteration: never repeated across solves
+    c->waited_k = 0;
+    if (c->direct_err) memset(c->direct_err, 0, 64);
     if (c->exchange2_wanted()) {
         // the state is initialised through RCCL (one-off); the iterations then run on the mailboxes
         LAMCHK(setup_direct(c));
         c->cg_direct = c->direct_ok;
-        c->epoch++;
-        if (c->direct_err) memset(c->direct_err, 0, 64);
     }
+    if (!c->rank_mode && c->total_shards == 1 && c->opt_fuse && c->opt_finalize) LAMCHK(ensure_mail(c, nullptr));
     if (c->exchange1_ok()) return do_cg_init_exchange1(c);
     c->cg_exchange1 = false;
     return dispatch(c, [&](auto impl) -> int {
@@ -1027,6 +1073,24 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
         c->gather_pending = false;
         const bool fin_a = producer_reduces(c, false), fin_b = producer_reduces(c, true);
         LAMCHK(reduce_step(c, false, true, true, fin_a));
+        if (!c->rank_mode && c->total_shards == 1 && c->opt_fuse && c->opt_finalize && c->mail != nullptr) {
+            // one shard: steps 2 and 3 in ONE launch; the r.r total travels through the context's own mailbox
+            ShardBase &s = c->sh[0];
+            LAMCHK(set_dev(c, s));
+            const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
+            const double *red; int nred;
+            red_source(c, s, false, true, fin_a, &red, &nred);
+            Finalize fr;
+            fr.active = 1; fr.mail = 1; fr.seq = seq; fr.slot = 0; fr.dst.n = 1; fr.dst.p[0] = &c->mail->rr[0];
+            BlockCounts nb;
+            for (auto &v : nb.n) v = 0;
+            hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, red, nred, s.sc, k, rel_error,
+                               (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fr,
+                               MailWait{nullptr, 0, 0, nullptr}, MailWait{c->mail->rr, 1, seq, c->direct_err}, plist_p(c), s.row0,
+                               (volatile int *)s.host_flags, no_post(), (const Mail *)c->mail, nb);
+            HIPCHK(c, hipGetLastError());
+            return 0;
+        }
         // 2. x, r update + partial r.r
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
@@ -1481,7 +1545,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             LAMCHK(set_dev(c, s0));
             HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
             harvest(slot);
-            if (c->cg_direct && *(volatile int *)c->direct_err != 0) break;     // reported after the sync below
+            if (c->direct_err && *(volatile int *)c->direct_err != 0) break;    // reported after the sync below
             const int stop_at = ((volatile int *)s0.host_flags)[1];
             // LAM_HIP_DEBUG_LEVEL_STOP: test hook that restores the timing-dependent decision ("any stop
             // seen so far") so that the stream-ordered RCCL test double can be shown to catch the rank
@@ -1497,7 +1561,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     }
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
-    if (c->cg_direct && c->direct_err && *c->direct_err != 0)
+    if (c->direct_err && *c->direct_err != 0)
         return fail(c, LAM_HIP_EHIP, "direct exchange: rank %d: a bounded wait for a peer expired (code %d: 2 = partial dot product, 3 = p slice; "
                                      "slot %d, expected tag %d:%d, saw %d:%d); the ranks are no longer in step", c->rank, c->direct_err[0],
                     c->direct_err[1], c->direct_err[4], c->direct_err[2], c->direct_err[5], c->direct_err[3]);
@@ -1878,6 +1942,7 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "finalize")) { c->opt_finalize = value; c->cg_ready = false; }
     else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
     else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
+    else if (!strcmp(name, "fuse_update")) c->opt_fuse = value;
     else if (!strcmp(name, "symmetric")) c->opt_symmetric = value;
     else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
     else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;
@@ -1900,6 +1965,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "finalize")) *value = c->opt_finalize;
     else if (!strcmp(name, "upload_staging")) *value = c->opt_upload_staging;
     else if (!strcmp(name, "reuse_matrix")) *value = c->opt_reuse_matrix;
+    else if (!strcmp(name, "fuse_update")) *value = c->opt_fuse;
     else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
     else if (!strcmp(name, "symmetric")) *value = c->opt_symmetric;
     else if (!strcmp(name, "symmetric_effective")) *value = c->symv_active() ? 1 : 0;

@@ -160,6 +160,8 @@ struct MailPost {                     // update_p: flags to raise after the p sl
     unsigned long long seq;
 };
 
+struct BlockCounts { int n[kMaxShards]; };   // update_p workgroups of every rank (p-slice flags to wait for)
+
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -205,9 +207,8 @@ __device__ __forceinline__ void publish_partial(double t, double *partial, const
 }
 
 // the reducer workgroup (every thread of it; workgroups wider than kBlock: the extra waves idle)
-__device__ __forceinline__ void reduce_partials(double *partial, const Finalize &f, double *s_red /*[kWaves]*/)
+__device__ __forceinline__ void reduce_partials(double *partial, int n /*compute workgroups*/, const Finalize &f, double *s_red /*[kWaves]*/)
 {
-    const int n = (int)gridDim.x - 1;
     const unsigned long long t0 = wall_clock64();
     bool timed_out = false;
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(partial);
@@ -351,7 +352,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
-    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, (int)gridDim.x - 1, a.fin, s_red); return; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -508,7 +509,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
-    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, (int)gridDim.x - 1, a.fin, s_red); return; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -676,7 +677,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
     __shared__ double s_red[kWaves];
 
     if (a.sc != nullptr && a.sc->stop) return;
-    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, (int)gridDim.x - 1, a.fin, s_red); return; }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -960,7 +961,7 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
 {
     __shared__ double s_red[kWaves];
     if (a.sc != nullptr && a.sc->stop) return;
-    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, a.fin, s_red); return; }
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, (int)gridDim.x - 1, a.fin, s_red); return; }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint64_t row = (uint64_t)blockIdx.x * kWaves + wave;
@@ -1083,7 +1084,7 @@ update_xr_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k,
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
-    if (is_reducer_block(fin)) { reduce_partials(partial, fin, s_red); return; }
+    if (is_reducer_block(fin)) { reduce_partials(partial, (int)gridDim.x - 1, fin, s_red); return; }
     const double pAp = mw.n > 0 ? mail_sum(mw, s_red) : block_sum_array(red, nred, s_red);
     const double rr = sc->rr[(k + 1) & 1];
     const double alpha_d = rr / pAp;
@@ -1154,11 +1155,8 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
 }
 
 // direct exchange: wait until every other rank's update_p workgroups have flagged their p slice for `seq`
-struct BlockCounts { int n[kMaxShards]; };
-__global__ void __launch_bounds__(kBlock)
-wait_p_kernel(const Mail *mine, int nranks, int rank, BlockCounts nb, unsigned long long seq, const CgScalars *sc, int *host_err)
+__device__ __forceinline__ void wait_p_flags(const Mail *mine, int nranks, int rank, const BlockCounts &nb, unsigned long long seq, int *host_err)
 {
-    if (sc->stop) return;
     const unsigned long long t0 = wall_clock64();
     for (int q = 0; q < nranks; q++) {
         if (q == rank) continue;
@@ -1176,6 +1174,93 @@ wait_p_kernel(const Mail *mine, int nranks, int rank, BlockCounts nb, unsigned l
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused vector step: update_xr_kernel + update_p_kernel in ONE launch (one shard, and the direct exchange).
+// What separates the two kernels is a grid-wide dependency -- r.r needs every workgroup's partial --, and that
+// is exactly what the reducer workgroup + mailbox machinery already provides inside a launch: the compute
+// workgroups publish their partials of r.r, the reducer workgroup posts the total {value, tag} (to every rank's
+// mailbox in the direct exchange, to the context's own mailbox with one shard), and the compute workgroups
+// pick it up with the same bounded poll they use for a remote rank.  All workgroups of the launch are resident
+// together (at most 256 + 2 of them), so nobody waits for a workgroup that cannot start.  Arithmetic, element
+// -> thread mapping and reduction order are those of the two kernels: results are bit-identical.
+// Roles by workgroup index: [0, ncompute) compute, ncompute reducer, ncompute + 1 (direct exchange without
+// the own-slice GEMV panel only) the WAITER that holds the launch open until the peers' p slices for the next
+// GEMV have arrived -- which makes wait_p_kernel unnecessary: 2 launches per iteration.
+// ---------------------------------------------------------------------------------------------
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
+                    const TV *p_loc, const TV *__restrict__ Ap, TV *__restrict__ x, TV *__restrict__ r, uint64_t n_loc,
+                    double *partial, int ncompute, Finalize fin, MailWait mw_pap, MailWait mw_rr, PtrList pdst, uint64_t row0,
+                    volatile int *host_flags, MailPost post, const Mail *mine, BlockCounts nb)
+{
+    __shared__ double s_red[kWaves];
+    if (sc->stop) return;
+    if ((int)blockIdx.x == ncompute) { reduce_partials(partial, ncompute, fin, s_red); return; }
+    const double bb = sc->bb;
+    if ((int)blockIdx.x > ncompute) {                   // waiter
+        const double rr_w = mail_sum(mw_rr, s_red);
+        if (sqrt(rr_w / bb) < rel_error) return;        // the solve stops here: nobody posts a p slice
+        wait_p_flags(mine, post.n, post.rank, nb, post.seq, mw_rr.host_err);
+        return;
+    }
+    // ---- update_xr_kernel
+    const double pAp = mw_pap.n > 0 ? mail_sum(mw_pap, s_red) : block_sum_array(red, nred, s_red);
+    const double rr = sc->rr[(k + 1) & 1];
+    const double alpha_d = rr / pAp;
+    const TV alpha = (TV)alpha_d;
+    double acc = 0.0;
+    const uint64_t stride = (uint64_t)ncompute * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
+        x[i] = alpha * p_loc[i] + x[i];
+        const TV ri = -alpha * Ap[i] + r[i];
+        r[i] = ri;
+        acc += (double)ri * (double)ri;
+    }
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0 && blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
+    publish_partial(t, partial, fin);
+    // ---- update_p_kernel
+    const double rr_new = mail_sum(mw_rr, s_red);
+    const double beta_d = rr_new / rr;
+    const bool stop = sqrt(rr_new / bb) < rel_error;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->rr[k & 1] = rr_new;
+        sc->beta = beta_d;
+        sc->iters = k;
+        if (host_flags != nullptr) {
+            host_flags[0] = k;
+            if (stop) host_flags[1] = k;
+        }
+        if (stop) sc->stop = 1;
+    }
+    if (stop) return;
+    const TV beta = (TV)beta_d;
+    if (post.n == 0) {
+        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
+            const TV pi = r[i] + beta * p_loc[i];
+            for (int j = 0; j < pdst.n; j++) reinterpret_cast<TV *>(pdst.p[j])[row0 + i] = pi;
+        }
+        return;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
+        const TV pi = r[i] + beta * p_loc[i];
+        for (int j = 0; j < pdst.n; j++)
+            __hip_atomic_store(reinterpret_cast<TV *>(pdst.p[j]) + row0 + i, pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)threadIdx.x < post.n && (int)threadIdx.x != post.rank)
+        st_sys(&post.mail[threadIdx.x]->pflag[post.rank][blockIdx.x], post.seq);
+}
+
+__global__ void __launch_bounds__(kBlock)
+wait_p_kernel(const Mail *mine, int nranks, int rank, BlockCounts nb, unsigned long long seq, const CgScalars *sc, int *host_err)
+{
+    if (sc->stop) return;
+    wait_p_flags(mine, nranks, rank, nb, seq, host_err);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--exchange", type=int, default=0)
     ap.add_argument("--finalize", type=int, default=1)
+    ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--tol", type=float, default=None)
     ap.add_argument("--chunk", type=int, default=0)
@@ -56,6 +57,7 @@ def main():
                 s.set_option("overlap", a.overlap)
                 s.set_option("exchange", a.exchange)
                 s.set_option("finalize", a.finalize)
+                s.set_option("fuse_update", a.fuse)
                 if a.chunk > 0:
                     s.cg_init()
                     done, conv, calls = 0, False, 0

@@ -557,3 +557,28 @@ def test_symmetric_option_preconditions(lam):
         s.generate_random_spd(4096, 5, 10.0)
         s.set_option("symmetric", 1)
         assert s.get_option("symmetric_effective") == 0   # single shard only
+
+
+@pytest.mark.parametrize("dtype_name,n,shards", [("F64", 1000, 1), ("F64", 4096, 1), ("F32", 2048, 1), ("F64", 3000, 3)])
+def test_launch_chain_variants_are_bit_identical(lam, dtype_name, n, shards):
+    """The iteration's vector work exists in three launch shapes -- fused update (one launch, the r.r total handed
+    over inside the launch through the context's mailbox), separate update_xr / update_p with the reducer
+    workgroup, and the round-1 chain with separate reduction launches (finalize = 0) -- which must be the same
+    arithmetic: identical iteration counts, residuals and solution bits.  (Several shards in one process always
+    use the two-kernel form; fuse_update is then ignored.)"""
+    dt = getattr(lam, dtype_name)
+    res = []
+    for fuse, fin in ((1, 1), (0, 1), (0, 0)):
+        with lam.Solver(dt, n_shards=shards, device_ids=[0] * shards) as s:
+            s.generate_random_spd(n, 5, 300.0)
+            s.generate_random_rhs(6)
+            s.set_option("fuse_update", fuse)
+            s.set_option("finalize", fin)
+            s.solve(400, 1e-9 if dtype_name == "F64" else 1e-5)
+            res.append((s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes(), s.true_residual()))
+            # continuing an interrupted solve in chunks gives the same bits as well
+            s.cg_init()
+            for _ in range(3):
+                s.cg_iterate(7, 0.0)
+            res[-1] += (s.solution().tobytes(),)
+    assert res[0] == res[1] == res[2]

@@ -101,16 +101,19 @@ def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, ov
 @pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), (4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
 def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path, P, n, mode):
     """exchange 2 sums the ranks' partial dot products with the same reduction tree as exchange 0, so the
-    two must produce the same bits: iteration count, residual and every element of x."""
+    two must produce the same bits: iteration count, residual and every element of x -- in all four launch shapes
+    of the direct exchange (own-slice GEMV panel or not; x/r/p updates fused into one launch, with the waiter
+    workgroup, or as two kernels behind wait_p_kernel)."""
     outs = []
-    for ex in (0, 2):
-        r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--exchange", ex, "--no-single")
+    for ex, overlap, fuse in ((0, 1, 1), (2, 1, 1), (2, 0, 1), (2, 1, 0), (2, 0, 0)):
+        r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--exchange", ex, "--overlap", overlap, "--fuse", fuse, "--no-single")
         _check_mock_stats(lines, P)
         os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
         outs.append(out)
-    a, b = outs
-    assert b["exchange_effective"] == [2] * P
-    assert (a["iters"], a["rel_err"], a["x_sha"]) == (b["iters"], b["rel_err"], b["x_sha"]), (a, b)
+    a = outs[0]
+    for b in outs[1:]:
+        assert b["exchange_effective"] == [2] * P
+        assert (a["iters"], a["rel_err"], a["x_sha"]) == (b["iters"], b["rel_err"], b["x_sha"]), (a, b)
 
 
 @pytest.mark.parametrize("P,n,mode,exchange,delay,chunk", [
