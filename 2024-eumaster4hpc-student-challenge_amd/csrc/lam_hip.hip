@@ -119,6 +119,7 @@ struct lam_hip_ctx {
     // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
     Mail *mail = nullptr;                       // own mailbox, fine-grained device memory
     bool mail_coarse = false;                   // ... or ordinary device memory (enough for one shard, not for peers)
+    MailSlot *bcast = nullptr;                  // [2] in-launch broadcast slots of update_fused_kernel (ordinary device memory)
     Mail *peer_mail[kMaxShards] = {};           // every rank's mailbox as seen from here (own included)
     void *peer_p[kMaxShards] = {};              // every rank's p replica as seen from here (own included)
     void *ipc_opened[2 * kMaxShards] = {};      // mappings to close again
@@ -740,6 +741,10 @@ int ensure_mail(lam_hip_ctx *c, bool *got_finegrained)
         HIPCHK(c, hipMemset(c->mail, 0, sizeof(Mail)));
     }
     if (got_finegrained) *got_finegrained = !c->mail_coarse;
+    if (c->bcast == nullptr) {
+        HIPCHK(c, hipMalloc((void **)&c->bcast, 256));
+        HIPCHK(c, hipMemset(c->bcast, 0, 256));
+    }
     if (c->direct_err == nullptr) {
         HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));
         memset(c->direct_err, 0, 64);
@@ -900,7 +905,7 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
             hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1 + (waiter ? 1 : 0)), dim3(kBlock), 0, s.stream,
                                (const double *)nullptr, 0, s.sc, k, rel_error, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x,
                                (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fb, MailWait{c->mail->pap, P, seq, c->direct_err},
-                               MailWait{c->mail->rr, P, seq, c->direct_err}, plf, s.row0, (volatile int *)s.host_flags, postf,
+                               MailWait{c->mail->rr, P, seq, c->direct_err}, c->bcast, plf, s.row0, (volatile int *)s.host_flags, postf,
                                (const Mail *)c->mail, nb);
             HIPCHK(c, hipGetLastError());
             if (waiter) c->waited_k = k;
@@ -1081,12 +1086,12 @@ int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
             const double *red; int nred;
             red_source(c, s, false, true, fin_a, &red, &nred);
             Finalize fr;
-            fr.active = 1; fr.mail = 1; fr.seq = seq; fr.slot = 0; fr.dst.n = 1; fr.dst.p[0] = &c->mail->rr[0];
+            fr.active = 1; fr.mail = 0; fr.seq = seq; fr.slot = 0; fr.dst.n = 0;      // one shard: the total goes straight to the broadcast slot
             BlockCounts nb;
             for (auto &v : nb.n) v = 0;
             hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, red, nred, s.sc, k, rel_error,
                                (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fr,
-                               MailWait{nullptr, 0, 0, nullptr}, MailWait{c->mail->rr, 1, seq, c->direct_err}, plist_p(c), s.row0,
+                               MailWait{nullptr, 0, 0, nullptr}, MailWait{c->mail->rr, 1, seq, c->direct_err}, c->bcast, plist_p(c), s.row0,
                                (volatile int *)s.host_flags, no_post(), (const Mail *)c->mail, nb);
             HIPCHK(c, hipGetLastError());
             return 0;
@@ -1228,6 +1233,7 @@ void lam_hip_destroy(lam_hip_ctx *c)
     close_direct(c);
     if (c->agree_buf) (void)hipFree(c->agree_buf);
     if (c->mail) (void)hipFree(c->mail);
+    if (c->bcast) (void)hipFree(c->bcast);
     if (c->direct_err) (void)hipHostFree(c->direct_err);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     for (auto &s : c->sh) {

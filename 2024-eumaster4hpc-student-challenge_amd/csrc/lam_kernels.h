@@ -207,7 +207,7 @@ __device__ __forceinline__ void publish_partial(double t, double *partial, const
 }
 
 // the reducer workgroup (every thread of it; workgroups wider than kBlock: the extra waves idle)
-__device__ __forceinline__ void reduce_partials(double *partial, int n /*compute workgroups*/, const Finalize &f, double *s_red /*[kWaves]*/)
+__device__ __forceinline__ double reduce_partials_sum(double *partial, int n /*compute workgroups*/, double *s_red /*[kWaves]*/)
 {
     const unsigned long long t0 = wall_clock64();
     bool timed_out = false;
@@ -249,18 +249,60 @@ __device__ __forceinline__ void reduce_partials(double *partial, int n /*compute
         take(i, std::integral_constant<int, 1>(), a);
         v += a[0];
     }
-    const double total = block_sum(v, s_red);
-    if (threadIdx.x == 0) {
-        if (!f.mail) {
-            for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
-        } else {
-            // direct exchange: value into every rank's mailbox, drain, then the tags
-            for (int j = 0; j < f.dst.n; j++)
-                st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->value_bits, (unsigned long long)__double_as_longlong(total));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int j = 0; j < f.dst.n; j++) st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->seq, f.seq);
-        }
+    return block_sum(v, s_red);
+}
+
+// thread 0 of the reducer workgroup: hand the shard's total to whoever consumes it (see Finalize)
+__device__ __forceinline__ void post_total(const Finalize &f, double total)
+{
+    if (threadIdx.x != 0) return;
+    if (!f.mail) {
+        for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
+    } else {
+        // direct exchange: value into every rank's mailbox, drain, then the tags
+        for (int j = 0; j < f.dst.n; j++)
+            st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->value_bits, (unsigned long long)__double_as_longlong(total));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int j = 0; j < f.dst.n; j++) st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->seq, f.seq);
     }
+}
+
+__device__ __forceinline__ void reduce_partials(double *partial, int n, const Finalize &f, double *s_red)
+{
+    post_total(f, reduce_partials_sum(partial, n, s_red));
+}
+
+// Hand-over INSIDE a launch (update_fused_kernel): the reducer workgroup publishes a scalar for the launch's
+// other workgroups in ordinary device memory -- value (agent-scope write-through store), drain, tag -- and they
+// poll the tag with agent-scope loads, which the memory-side cache serves.  (Letting every workgroup poll the
+// UNCACHED mailbox instead -- 256 pollers on one DRAM location -- made the writer's own store queue behind them:
+// measured +70 us per iteration at N=65536.)  One thread polls; the value reaches the workgroup through block_sum.
+__device__ __forceinline__ void bcast_post(MailSlot *slot, double value, unsigned long long seq)
+{
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(&slot->value_bits, (unsigned long long)__double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double bcast_wait(const MailSlot *slot, unsigned long long seq, int *host_err, double *s_red)
+{
+    double v = 0.0;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long seen;
+        while ((seen = __hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != seq) {
+            if (*(volatile int *)host_err != 0) break;
+            if (wall_clock64() - t0 > kFinalizeTimeoutTicks) {
+                host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
+                host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
+                *(volatile int *)host_err = 4;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        v = __longlong_as_double((long long)__hip_atomic_load(&slot->value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return block_sum(v, s_red);
 }
 
 // arm the slots (cg_init, and whenever a launch without a reducer may have written plain values)
@@ -1180,9 +1222,9 @@ __device__ __forceinline__ void wait_p_flags(const Mail *mine, int nranks, int r
 // Fused vector step: update_xr_kernel + update_p_kernel in ONE launch (one shard, and the direct exchange).
 // What separates the two kernels is a grid-wide dependency -- r.r needs every workgroup's partial --, and that
 // is exactly what the reducer workgroup + mailbox machinery already provides inside a launch: the compute
-// workgroups publish their partials of r.r, the reducer workgroup posts the total {value, tag} (to every rank's
-// mailbox in the direct exchange, to the context's own mailbox with one shard), and the compute workgroups
-// pick it up with the same bounded poll they use for a remote rank.  All workgroups of the launch are resident
+// workgroups publish their partials of r.r, the reducer workgroup turns them into the total -- with the direct
+// exchange by way of every rank's mailbox, which it alone polls -- and hands {value, tag} to the launch's other
+// workgroups through a broadcast slot in ordinary device memory, which they poll (bounded) at agent scope.  All workgroups of the launch are resident
 // together (at most 256 + 2 of them), so nobody waits for a workgroup that cannot start.  Arithmetic, element
 // -> thread mapping and reduction order are those of the two kernels: results are bit-identical.
 // Roles by workgroup index: [0, ncompute) compute, ncompute reducer, ncompute + 1 (direct exchange without
@@ -1193,21 +1235,35 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
                     const TV *p_loc, const TV *__restrict__ Ap, TV *__restrict__ x, TV *__restrict__ r, uint64_t n_loc,
-                    double *partial, int ncompute, Finalize fin, MailWait mw_pap, MailWait mw_rr, PtrList pdst, uint64_t row0,
-                    volatile int *host_flags, MailPost post, const Mail *mine, BlockCounts nb)
+                    double *partial, int ncompute, Finalize fin, MailWait mw_pap, MailWait mw_rr, MailSlot *bc /*[2], local*/,
+                    PtrList pdst, uint64_t row0, volatile int *host_flags, MailPost post, const Mail *mine, BlockCounts nb)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
-    if ((int)blockIdx.x == ncompute) { reduce_partials(partial, ncompute, fin, s_red); return; }
+    const unsigned long long seq = mw_rr.seq;
+    int *host_err = mw_rr.host_err;
+    if ((int)blockIdx.x == ncompute) {
+        // reducer: the ONLY workgroup that polls the (uncached) mailbox; everything it learns goes to the launch's
+        // other workgroups through the two local broadcast slots
+        if (mw_pap.n > 0) bcast_post(&bc[0], mail_sum(mw_pap, s_red), seq);          // direct exchange: p.Ap of all ranks
+        const double local = reduce_partials_sum(partial, ncompute, s_red);           // this shard's r.r
+        if (fin.mail) {
+            post_total(fin, local);                                                    // ... to every rank's mailbox
+            bcast_post(&bc[1], mail_sum(mw_rr, s_red), seq);                           // r.r of all ranks
+        } else {
+            bcast_post(&bc[1], local, seq);                                            // one shard
+        }
+        return;
+    }
     const double bb = sc->bb;
     if ((int)blockIdx.x > ncompute) {                   // waiter
-        const double rr_w = mail_sum(mw_rr, s_red);
+        const double rr_w = bcast_wait(&bc[1], seq, host_err, s_red);
         if (sqrt(rr_w / bb) < rel_error) return;        // the solve stops here: nobody posts a p slice
-        wait_p_flags(mine, post.n, post.rank, nb, post.seq, mw_rr.host_err);
+        wait_p_flags(mine, post.n, post.rank, nb, post.seq, host_err);
         return;
     }
     // ---- update_xr_kernel
-    const double pAp = mw_pap.n > 0 ? mail_sum(mw_pap, s_red) : block_sum_array(red, nred, s_red);
+    const double pAp = mw_pap.n > 0 ? bcast_wait(&bc[0], seq, host_err, s_red) : block_sum_array(red, nred, s_red);
     const double rr = sc->rr[(k + 1) & 1];
     const double alpha_d = rr / pAp;
     const TV alpha = (TV)alpha_d;
@@ -1221,9 +1277,9 @@ update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int
     }
     const double t = block_sum(acc, s_red);
     if (threadIdx.x == 0 && blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
-    publish_partial(t, partial, fin);
+    if (threadIdx.x == 0) __hip_atomic_store(partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- update_p_kernel
-    const double rr_new = mail_sum(mw_rr, s_red);
+    const double rr_new = bcast_wait(&bc[1], seq, host_err, s_red);
     const double beta_d = rr_new / rr;
     const bool stop = sqrt(rr_new / bb) < rel_error;
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -19,8 +19,10 @@ def main():
         s.generate_random_spd(n, 11, 1e6)
         s.generate_random_rhs(12)
         print(f"rccl version {lam.rccl_version()}  N={n}  kernel {s.gemv_kernel_name()}")
-        for exchange, finalize, overlap in ((0, 0, 1), (0, 1, 1), (0, 1, 0), (1, 0, 1), (1, 1, 1)):
+        for exchange, finalize, overlap, fuse in ((0, 0, 1, 0), (0, 1, 1, 0), (0, 1, 0, 0), (1, 0, 1, 0), (1, 1, 1, 0),
+                                                  (2, 1, 1, 0), (2, 1, 0, 0), (2, 1, 1, 1), (2, 1, 0, 1)):
             s.set_option("exchange", exchange); s.set_option("finalize", finalize); s.set_option("overlap", overlap)
+            s.set_option("fuse_update", fuse)
             best = None
             for _ in range(3):
                 s.cg_init()
@@ -28,14 +30,16 @@ def main():
                 st = s.cg_iterate(iters, 0.0)
                 if best is None or st["t_iter"] < best["t_iter"]:
                     best = st
-            print(f"exchange={exchange} finalize={finalize} overlap={overlap}: {best['t_iter']*1e3:.4f} ms/iter, gemv {best['t_gemv']*1e3:.4f} ms, "
+            print(f"exchange={exchange} finalize={finalize} overlap={overlap} fuse={fuse}: {best['t_iter']*1e3:.4f} ms/iter, gemv {best['t_gemv']*1e3:.4f} ms, "
                   f"other {(best['t_iter']-best['t_gemv'])*1e6:.1f} us", flush=True)
     # single-shard chain (no RCCL) for reference
     os.environ.pop("LAM_HIP_FORCE_RCCL")
     with lam.Solver(lam.F64) as s:
         s.generate_random_spd(n, 11, 1e6); s.generate_random_rhs(12)
-        s.cg_init(); s.cg_iterate(10, 0.0); st = s.cg_iterate(iters, 0.0)
-        print(f"single shard (no exchange): {st['t_iter']*1e3:.4f} ms/iter, gemv {st['t_gemv']*1e3:.4f} ms, other {(st['t_iter']-st['t_gemv'])*1e6:.1f} us")
+        for fuse in (0, 1, 0, 1):
+            s.set_option("fuse_update", fuse)
+            s.cg_init(); s.cg_iterate(10, 0.0); st = s.cg_iterate(iters, 0.0)
+            print(f"single shard (no exchange) fuse={fuse}: {st['t_iter']*1e3:.4f} ms/iter, gemv {st['t_gemv']*1e3:.4f} ms, other {(st['t_iter']-st['t_gemv'])*1e6:.1f} us")
 
 
 if __name__ == "__main__":
