@@ -119,7 +119,7 @@ struct lam_hip_ctx {
     // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
     Mail *mail = nullptr;                       // own mailbox, fine-grained device memory
     bool mail_coarse = false;                   // ... or ordinary device memory (enough for one shard, not for peers)
-    MailSlot *bcast = nullptr;                  // [2] in-launch broadcast slots of update_fused_kernel (ordinary device memory)
+    BcastLine *bcast = nullptr;                 // [2][kBcastLines] in-launch broadcast lines of update_fused_kernel (ordinary device memory)
     Mail *peer_mail[kMaxShards] = {};           // every rank's mailbox as seen from here (own included)
     void *peer_p[kMaxShards] = {};              // every rank's p replica as seen from here (own included)
     void *ipc_opened[2 * kMaxShards] = {};      // mappings to close again
@@ -742,8 +742,8 @@ int ensure_mail(lam_hip_ctx *c, bool *got_finegrained)
     }
     if (got_finegrained) *got_finegrained = !c->mail_coarse;
     if (c->bcast == nullptr) {
-        HIPCHK(c, hipMalloc((void **)&c->bcast, 256));
-        HIPCHK(c, hipMemset(c->bcast, 0, 256));
+        HIPCHK(c, hipMalloc((void **)&c->bcast, 2 * kBcastLines * sizeof(BcastLine)));
+        HIPCHK(c, hipMemset(c->bcast, 0, 2 * kBcastLines * sizeof(BcastLine)));
     }
     if (c->direct_err == nullptr) {
         HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));

@@ -108,12 +108,28 @@ struct PtrList {                      // destinations of a replicated store (one
 //     bit-identical to a separate reduction launch --, writes the total to slot `slot` of every
 //     destination and re-arms the slots with the sentinel for the next launch.
 // The reducer is dispatched after the compute workgroups and only ever waits for workgroups that are
-// already running; its spin is bounded (kFinalizeTimeoutTicks) and ends in a NaN total, never in a hang.
+// already running; its spin is bounded (SpinGuard) and ends in a NaN total, never in a hang.
 // (An arrival counter drawn by every workgroup -- store, drain, fetch_add -- was measured first: the
 // two memory round trips at the end of each of 11584 GEMV workgroups cost 45 us per launch, four times
 // what the removed launch had cost.)
 constexpr unsigned long long kPartialSentinel = 0x7ff8dead5eedbeefull;   // quiet NaN with a payload nothing computes
-constexpr unsigned long long kFinalizeTimeoutTicks = 5ull * 100000000ull; // wall_clock64() runs at 100 MHz: 5 s
+// Bounded spinning with nothing slow on the fast path: the CU-local shader clock (clock64(), s_memtime -- not the
+// shared constant-rate counter behind wall_clock64()) and the abort word are looked at once every 256 failed polls;
+// limit ~5 s at 2.4 GHz (longer if the clock is lower -- it only bounds a wait that should never expire).
+constexpr unsigned long long kSpinTimeoutCycles = 12000000000ull;
+struct SpinGuard {
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    // once per failed poll; true once every 256 polls: the moment to look at slow things (the clock, and the
+    // abort word in PINNED HOST memory -- a PCIe read: 256 workgroups doing one per poll cost 45-130 us per launch)
+    __device__ __forceinline__ bool slow_path() { return (++spins & 255u) == 0; }
+    __device__ __forceinline__ bool expired()          // only on the slow path
+    {
+        const unsigned long long now = (unsigned long long)clock64();
+        if (t0 == 0) { t0 = now | 1ull; return false; }
+        return now - t0 > kSpinTimeoutCycles;
+    }
+};
 
 struct Finalize {
     int active;                       // 0: no in-kernel reduction (the launch has no reducer workgroup)
@@ -136,7 +152,7 @@ struct Finalize {
 //     drains them, and raises pflag[rank][workgroup] = seq in every mailbox; a 1-workgroup wait_p_kernel
 //     in front of the next GEMV (behind its own-slice panel) polls those flags: the direct all-gather.
 // Mailboxes are fine-grained (uncached) device memory; tags never repeat (epoch), so nothing is ever
-// reset and a slot can be read by any number of workgroups.  Every poll is bounded (kFinalizeTimeoutTicks):
+// reset and a slot can be read by any number of workgroups.  Every poll is bounded (SpinGuard):
 // a peer that never shows up ends in an error flag in pinned host memory, not in a hang.
 // ---------------------------------------------------------------------------------------------
 struct MailSlot {
@@ -178,16 +194,18 @@ __device__ __forceinline__ double mail_sum(const MailWait &w, double *s_red)
     double v = 0.0;
     if ((int)threadIdx.x < w.n) {
         const MailSlot *m = w.slots + threadIdx.x;
-        const unsigned long long t0 = wall_clock64();
+        SpinGuard guard;
         unsigned long long seen;
         while ((seen = ld_sys(&m->seq)) != w.seq) {
+            if (guard.slow_path()) {
             // an expired wait anywhere (this kernel or an earlier one) ends all waiting: the solve has failed
             if (*(volatile int *)w.host_err != 0) break;
-            if (wall_clock64() - t0 > kFinalizeTimeoutTicks) {
+            if (guard.expired()) {
                 w.host_err[1] = (int)threadIdx.x; w.host_err[2] = (int)(unsigned)w.seq; w.host_err[3] = (int)(unsigned)seen;
                 w.host_err[4] = (int)(w.seq >> 32); w.host_err[5] = (int)(seen >> 32);
                 *(volatile int *)w.host_err = 2;
                 break;
+            }
             }
             __builtin_amdgcn_s_sleep(4);
         }
@@ -209,7 +227,7 @@ __device__ __forceinline__ void publish_partial(double t, double *partial, const
 // the reducer workgroup (every thread of it; workgroups wider than kBlock: the extra waves idle)
 __device__ __forceinline__ double reduce_partials_sum(double *partial, int n /*compute workgroups*/, double *s_red /*[kWaves]*/)
 {
-    const unsigned long long t0 = wall_clock64();
+    SpinGuard guard;
     bool timed_out = false;
     unsigned long long *slots = reinterpret_cast<unsigned long long *>(partial);
     auto ld = [&](int j) { return __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -228,7 +246,7 @@ __device__ __forceinline__ double reduce_partials_sum(double *partial, int n /*c
                 if (b[k] == kPartialSentinel) { b[k] = ld(base + k * kBlock); pending |= b[k] == kPartialSentinel; }
             if (pending) {
                 __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > kFinalizeTimeoutTicks) timed_out = true;
+                if (guard.slow_path() && guard.expired()) timed_out = true;
             }
         }
 #pragma unroll
@@ -274,31 +292,41 @@ __device__ __forceinline__ void reduce_partials(double *partial, int n, const Fi
 
 // Hand-over INSIDE a launch (update_fused_kernel): the reducer workgroup publishes a scalar for the launch's
 // other workgroups in ordinary device memory -- value (agent-scope write-through store), drain, tag -- and they
-// poll the tag with agent-scope loads, which the memory-side cache serves.  (Letting every workgroup poll the
-// UNCACHED mailbox instead -- 256 pollers on one DRAM location -- made the writer's own store queue behind them:
-// measured +70 us per iteration at N=65536.)  One thread polls; the value reaches the workgroup through block_sum.
-__device__ __forceinline__ void bcast_post(MailSlot *slot, double value, unsigned long long seq)
+// poll the tag with agent-scope loads.  One thread polls; the value reaches the workgroup through block_sum.
+// Every listener has a LINE OF ITS OWN (BcastLine, 128 B): hundreds of workgroups polling one word serialise at the
+// memory side and the writer's store queues behind them -- measured 0.2-0.35 us per polling workgroup, 45-90 us per
+// iteration with 256 of them.  The reducer's threads write the lines in parallel.
+constexpr int kBcastLines = 264;      // >= 256 compute workgroups + the waiter
+struct BcastLine {
+    MailSlot s;
+    char pad[128 - sizeof(MailSlot)];
+};
+__device__ __forceinline__ void bcast_post(BcastLine *lines, int nlisteners, double value, unsigned long long seq)
 {
-    if (threadIdx.x != 0) return;
-    __hip_atomic_store(&slot->value_bits, (unsigned long long)__double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = threadIdx.x; t < nlisteners; t += kBlock)
+        __hip_atomic_store(&lines[t].s.value_bits, (unsigned long long)__double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = threadIdx.x; t < nlisteners; t += kBlock)
+        __hip_atomic_store(&lines[t].s.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double bcast_wait(const MailSlot *slot, unsigned long long seq, int *host_err, double *s_red)
+__device__ __forceinline__ double bcast_wait(const BcastLine *line, unsigned long long seq, int *host_err, double *s_red)
 {
+    const MailSlot *slot = &line->s;
     double v = 0.0;
     if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
+        SpinGuard guard;
         unsigned long long seen;
         while ((seen = __hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != seq) {
+            if (guard.slow_path()) {
             if (*(volatile int *)host_err != 0) break;
-            if (wall_clock64() - t0 > kFinalizeTimeoutTicks) {
+            if (guard.expired()) {
                 host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
                 host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
                 *(volatile int *)host_err = 4;
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_s_sleep(4);
         }
         v = __longlong_as_double((long long)__hip_atomic_load(&slot->value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
@@ -1199,18 +1227,20 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
 // direct exchange: wait until every other rank's update_p workgroups have flagged their p slice for `seq`
 __device__ __forceinline__ void wait_p_flags(const Mail *mine, int nranks, int rank, const BlockCounts &nb, unsigned long long seq, int *host_err)
 {
-    const unsigned long long t0 = wall_clock64();
+    SpinGuard guard;
     for (int q = 0; q < nranks; q++) {
         if (q == rank) continue;
         for (int b = threadIdx.x; b < nb.n[q]; b += kBlock) {
             unsigned long long seen;
             while ((seen = ld_sys(&mine->pflag[q][b])) != seq) {
+                if (guard.slow_path()) {
                 if (*(volatile int *)host_err != 0) return;
-                if (wall_clock64() - t0 > kFinalizeTimeoutTicks) {
+                if (guard.expired()) {
                     host_err[1] = q * 1000 + b; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
                     host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
                     *(volatile int *)host_err = 3;
                     return;
+                }
                 }
                 __builtin_amdgcn_s_sleep(4);
             }
@@ -1227,7 +1257,7 @@ __device__ __forceinline__ void wait_p_flags(const Mail *mine, int nranks, int r
 // workgroups through a broadcast slot in ordinary device memory, which they poll (bounded) at agent scope.  All workgroups of the launch are resident
 // together (at most 256 + 2 of them), so nobody waits for a workgroup that cannot start.  Arithmetic, element
 // -> thread mapping and reduction order are those of the two kernels: results are bit-identical.
-// Roles by workgroup index: [0, ncompute) compute, ncompute reducer, ncompute + 1 (direct exchange without
+// Roles by workgroup index: 0 reducer, [1, ncompute] compute, ncompute + 1 (direct exchange without
 // the own-slice GEMV panel only) the WAITER that holds the launch open until the peers' p slices for the next
 // GEMV have arrived -- which makes wait_p_kernel unnecessary: 2 launches per iteration.
 // ---------------------------------------------------------------------------------------------
@@ -1235,54 +1265,58 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
                     const TV *p_loc, const TV *__restrict__ Ap, TV *__restrict__ x, TV *__restrict__ r, uint64_t n_loc,
-                    double *partial, int ncompute, Finalize fin, MailWait mw_pap, MailWait mw_rr, MailSlot *bc /*[2], local*/,
+                    double *partial, int ncompute, Finalize fin, MailWait mw_pap, MailWait mw_rr, BcastLine *bc /*[2][kBcastLines], local*/,
                     PtrList pdst, uint64_t row0, volatile int *host_flags, MailPost post, const Mail *mine, BlockCounts nb)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
     const unsigned long long seq = mw_rr.seq;
     int *host_err = mw_rr.host_err;
-    if ((int)blockIdx.x == ncompute) {
+    // workgroup 0 is the reducer (dispatched first: everybody else ends up waiting for it), 1..ncompute compute,
+    // ncompute + 1 the waiter
+    const int cb = (int)blockIdx.x - 1;
+    if (blockIdx.x == 0) {
         // reducer: the ONLY workgroup that polls the (uncached) mailbox; everything it learns goes to the launch's
         // other workgroups through the two local broadcast slots
-        if (mw_pap.n > 0) bcast_post(&bc[0], mail_sum(mw_pap, s_red), seq);          // direct exchange: p.Ap of all ranks
+        const int nl = (int)gridDim.x - 1;                                             // listeners: compute workgroups (+ waiter)
+        if (mw_pap.n > 0) bcast_post(bc, nl, mail_sum(mw_pap, s_red), seq);            // direct exchange: p.Ap of all ranks
         const double local = reduce_partials_sum(partial, ncompute, s_red);           // this shard's r.r
         if (fin.mail) {
             post_total(fin, local);                                                    // ... to every rank's mailbox
-            bcast_post(&bc[1], mail_sum(mw_rr, s_red), seq);                           // r.r of all ranks
+            bcast_post(bc + kBcastLines, nl, mail_sum(mw_rr, s_red), seq);             // r.r of all ranks
         } else {
-            bcast_post(&bc[1], local, seq);                                            // one shard
+            bcast_post(bc + kBcastLines, nl, local, seq);                              // one shard
         }
         return;
     }
     const double bb = sc->bb;
-    if ((int)blockIdx.x > ncompute) {                   // waiter
-        const double rr_w = bcast_wait(&bc[1], seq, host_err, s_red);
+    if (cb >= ncompute) {                               // waiter
+        const double rr_w = bcast_wait(bc + kBcastLines + cb, seq, host_err, s_red);
         if (sqrt(rr_w / bb) < rel_error) return;        // the solve stops here: nobody posts a p slice
         wait_p_flags(mine, post.n, post.rank, nb, post.seq, host_err);
         return;
     }
     // ---- update_xr_kernel
-    const double pAp = mw_pap.n > 0 ? bcast_wait(&bc[0], seq, host_err, s_red) : block_sum_array(red, nred, s_red);
+    const double pAp = mw_pap.n > 0 ? bcast_wait(bc + cb, seq, host_err, s_red) : block_sum_array(red, nred, s_red);
     const double rr = sc->rr[(k + 1) & 1];
     const double alpha_d = rr / pAp;
     const TV alpha = (TV)alpha_d;
     double acc = 0.0;
     const uint64_t stride = (uint64_t)ncompute * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
+    for (uint64_t i = (uint64_t)cb * kBlock + threadIdx.x; i < n_loc; i += stride) {
         x[i] = alpha * p_loc[i] + x[i];
         const TV ri = -alpha * Ap[i] + r[i];
         r[i] = ri;
         acc += (double)ri * (double)ri;
     }
     const double t = block_sum(acc, s_red);
-    if (threadIdx.x == 0 && blockIdx.x == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
-    if (threadIdx.x == 0) __hip_atomic_store(partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && cb == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
+    if (threadIdx.x == 0) __hip_atomic_store(partial + cb, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- update_p_kernel
-    const double rr_new = bcast_wait(&bc[1], seq, host_err, s_red);
+    const double rr_new = bcast_wait(bc + kBcastLines + cb, seq, host_err, s_red);
     const double beta_d = rr_new / rr;
     const bool stop = sqrt(rr_new / bb) < rel_error;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (cb == 0 && threadIdx.x == 0) {
         sc->rr[k & 1] = rr_new;
         sc->beta = beta_d;
         sc->iters = k;
@@ -1295,13 +1329,13 @@ update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int
     if (stop) return;
     const TV beta = (TV)beta_d;
     if (post.n == 0) {
-        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
+        for (uint64_t i = (uint64_t)cb * kBlock + threadIdx.x; i < n_loc; i += stride) {
             const TV pi = r[i] + beta * p_loc[i];
             for (int j = 0; j < pdst.n; j++) reinterpret_cast<TV *>(pdst.p[j])[row0 + i] = pi;
         }
         return;
     }
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_loc; i += stride) {
+    for (uint64_t i = (uint64_t)cb * kBlock + threadIdx.x; i < n_loc; i += stride) {
         const TV pi = r[i] + beta * p_loc[i];
         for (int j = 0; j < pdst.n; j++)
             __hip_atomic_store(reinterpret_cast<TV *>(pdst.p[j]) + row0 + i, pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1309,7 +1343,7 @@ update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if ((int)threadIdx.x < post.n && (int)threadIdx.x != post.rank)
-        st_sys(&post.mail[threadIdx.x]->pflag[post.rank][blockIdx.x], post.seq);
+        st_sys(&post.mail[threadIdx.x]->pflag[post.rank][cb], post.seq);
 }
 
 __global__ void __launch_bounds__(kBlock)
