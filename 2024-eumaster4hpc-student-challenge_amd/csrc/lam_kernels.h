@@ -6,7 +6,7 @@
 //   and the CPU members dot/axpby/gemv, LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:446-508.
 //
 // Design:
-//   * one CG iteration = 3 launches on a shard:
+//   * one CG iteration = 3 launches on a shard (2 where update_fused_kernel applies: one shard, direct exchange):
 //       gemv_coop_kernel   Ap_loc = A_loc p          (+ per-workgroup partials of p.Ap)
 //       update_xr_kernel   alpha = rr/(p.Ap); x += alpha p; r -= alpha Ap   (+ partials of r.r)
 //       update_p_kernel    rr' = r.r; beta = rr'/rr; stop test; p_slice = r + beta p  (stored into
