@@ -187,6 +187,13 @@ def main():
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: native libraries print there too (RCCL writes a five-line version banner to
+    # stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON
+    # line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # the host driver on these nodes only supports dmabuf IPC; RCCL across processes needs this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # one node (the contract: N GPUs of ONE node, rendezvous on 127.0.0.1): RCCL's bootstrap sockets go over
@@ -418,7 +425,8 @@ def main():
         cb["sample"] += f"; value = measured it/s x ({cb['sample_n']}/{n})^2 to the workload's N"
         out["cpu_baseline"] = cb
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()

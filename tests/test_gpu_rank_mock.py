@@ -283,3 +283,23 @@ def test_bench_survives_a_failing_direct_exchange(mock_mp_lib, tmp_path, hook, e
     for k in ("allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap"):
         assert out["exchange_modes"][k]["value"] > 0
     assert out["value"] > 0 and "direct" not in out["config"]["parallelism"]
+
+
+def test_bench_stdout_is_one_json_line_with_real_rccl(tmp_path):
+    """`torch.distributed.run --nproc-per-node 1 bench.py` with LAM_HIP_FORCE_RCCL=1: every exchange runs through the
+    REAL librccl on a 1-rank communicator.  RCCL prints a version banner to stdout when the communicator is created;
+    the driver expects stdout to be the one JSON line, nothing else."""
+    env = dict(os.environ, LAM_HIP_FORCE_RCCL="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LD_PRELOAD", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 100), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10",
+           "--warmup", "2", "--order", "8192"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["host_plumbing"]["rccl_version"] > 20000 and out["host_plumbing"]["torch_imported"] is False
+    assert set(out["exchange_modes"]) >= {"allgather_x2+allgather_p", "allgather_Ap", "direct_mailboxes"}
+    vals = [m["rel_residual_true"] for m in out["exchange_modes"].values() if "rel_residual_true" in m]
+    assert all(abs(v / vals[0] - 1) < 1e-6 for v in vals)
