@@ -1212,7 +1212,17 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
             return fail(nullptr, LAM_HIP_ERCCL, "ncclGetUniqueId failed");
         }
         (void)hipSetDevice(device_id);
+        // RCCL writes a five-line version banner to STDOUT when a communicator is created; the callers' stdout is
+        // a protocol (the drivers' CSV line, bench.py's JSON line), so it goes to stderr for the duration of the call
+        fflush(stdout);
+        const int saved_stdout = dup(1);
+        if (saved_stdout >= 0) (void)dup2(2, 1);
         ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+        if (saved_stdout >= 0) {
+            fflush(stdout);
+            (void)dup2(saved_stdout, 1);
+            (void)close(saved_stdout);
+        }
         if (r != ncclSuccess) {
             for (auto &s : c->sh) { free_shard(s); release_handles(s); }
             return fail(nullptr, LAM_HIP_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));

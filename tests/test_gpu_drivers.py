@@ -135,6 +135,17 @@ def test_rank_mode_collectives_single_rank(lam, oracle, monkeypatch):
     assert np.max(np.abs(y - oracle.gemv(A, b))) <= 1e-13 * np.max(np.abs(A) @ np.abs(b))
 
 
+def test_driver_csv_is_clean_with_real_rccl(tmp_path):
+    """LAM_HIP_FORCE_RCCL=1: the getopt driver through the REAL librccl (1-rank communicator).  RCCL prints a version
+    banner to stdout at communicator creation; the driver's stdout must still be exactly the reference's CSV line."""
+    r = _run([RCCL_EXE, "-s", "4096", "-i", "15", "-o", str(tmp_path / "sol.bin")], env={"LAM_HIP_FORCE_RCCL": "1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    f = lines[0].split(",")
+    assert f[0] == "4096" and int(f[7]) == 16 and abs(float(f[8]) / 0.000368282 - 1) < 1e-5 and float(f[4]) > 0   # comm-init column
+
+
 def test_mpi_bootstrapped_driver_single_rank(tmp_path):
     """Optional build (`make mpi`): MPI_Init + MPI_Bcast of the RCCL id, the reference NCCL variant's
     bootstrap (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:320-327).  One rank under mpiexec."""
