@@ -1206,7 +1206,9 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     if (c->rank_mode) {
         const double t0 = now_s();
         ncclUniqueId id;
-        if (unique_id) memcpy(&id, unique_id, sizeof id);
+        // a 1-rank communicator (LAM_HIP_FORCE_RCCL) has nobody to share an id with: make one here, whatever the
+        // caller passed (the C++ class hands over an all-zero buffer when the launch has a single rank)
+        if (unique_id && nranks > 1) memcpy(&id, unique_id, sizeof id);
         else if (ncclGetUniqueId(&id) != ncclSuccess) {
             for (auto &s : c->sh) { free_shard(s); release_handles(s); }
             return fail(nullptr, LAM_HIP_ERCCL, "ncclGetUniqueId failed");
