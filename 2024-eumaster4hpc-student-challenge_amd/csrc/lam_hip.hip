@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -194,6 +195,34 @@ void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
     *row0 = base * (uint64_t)q;
     *nrows = base + ((q == P - 1) ? n % (uint64_t)P : 0);
 }
+
+// File descriptor 1 points at stderr while at least one of these exists.  Counted under a lock: contexts may be
+// created from several threads at once (the ranks-as-threads test double), and the first one in must be the one
+// that remembers the real stdout, the last one out the one that restores it.
+struct StdoutToStderr {
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static int &depth() { static int d = 0; return d; }
+    static int &saved() { static int fd = -1; return fd; }
+    StdoutToStderr()
+    {
+        std::lock_guard<std::mutex> lk(mu());
+        if (depth()++ == 0) {
+            fflush(stdout);
+            saved() = dup(1);
+            if (saved() >= 0) (void)dup2(2, 1);
+        }
+    }
+    ~StdoutToStderr()
+    {
+        std::lock_guard<std::mutex> lk(mu());
+        if (--depth() == 0 && saved() >= 0) {
+            fflush(stdout);
+            (void)dup2(saved(), 1);
+            (void)close(saved());
+            saved() = -1;
+        }
+    }
+};
 
 // temporaries of one call: released on every exit path (HIPCHK returns from the middle of a function)
 struct DevBuf {
@@ -1216,14 +1245,10 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
         (void)hipSetDevice(device_id);
         // RCCL writes a five-line version banner to STDOUT when a communicator is created; the callers' stdout is
         // a protocol (the drivers' CSV line, bench.py's JSON line), so it goes to stderr for the duration of the call
-        fflush(stdout);
-        const int saved_stdout = dup(1);
-        if (saved_stdout >= 0) (void)dup2(2, 1);
-        ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
-        if (saved_stdout >= 0) {
-            fflush(stdout);
-            (void)dup2(saved_stdout, 1);
-            (void)close(saved_stdout);
+        ncclResult_t r;
+        {
+            StdoutToStderr quiet;
+            r = ncclCommInitRank(&c->comm, nranks, id, rank);
         }
         if (r != ncclSuccess) {
             for (auto &s : c->sh) { free_shard(s); release_handles(s); }
