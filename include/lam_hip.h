@@ -219,6 +219,8 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *   "fuse_update"   one shard, and exchange 2: 1 (default) = the x, r and p updates of an iteration are ONE launch (the
  *                   r.r total is handed over inside the launch); with exchange 2 and overlap 0 that launch also waits
  *                   for the peers' p slices, so an iteration is two launches.  0 = two kernels.  Same bits either way.
+ *   "reuse_matrix"  1 (default) = lam_hip_set_problem keeps the matrix allocation when it is large enough for the new
+ *                   problem (grow-only: a context never hands tens of GB back between problems); 0 = free + allocate.
  *   "upload_staging" lam_hip_upload_rows: 1 = copy through two pinned staging buffers (host memcpy overlapped
  *                   with the DMA); 0 (default) = hand the caller's pages to the runtime directly.
  *   "collectives_enqueued" (get only) RCCL calls this context has enqueued so far -- equal on all ranks.
