@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -30,9 +31,11 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
+#include <sched.h>
 #include <unistd.h>
 
 #include "../../include/lam_hip.h"
@@ -75,15 +78,16 @@ struct ShardBase {
     int part_gemv_cap = 0;       // entries allocated behind part_gemv
     CgScalars *sc = nullptr;     // device scalars
     CgScalars *sc_host = nullptr;// pinned mirror (filled by an async copy at the end of a call)
-    int *host_flags = nullptr;   // pinned, device-visible: [0] last finished iteration, [1] stop
+    int *host_flags = nullptr;   // pinned, device-visible progress word (lam_kernels.h, post_progress): low half = last
+                                 // finished iteration, high half = the stopping iteration (0 = none)
     int gemv_blocks = 0, vec_blocks = 0;
     hipStream_t comm_stream = nullptr;                          // rank mode: the all-gather of p runs here
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_p = nullptr;  // cross-shard ordering
     hipEvent_t ev_gathered = nullptr;                           // all-gather on comm_stream finished
-    hipEvent_t ev_lag[kLag] = {};
     hipEvent_t ev_g0[kLag] = {}, ev_g1[kLag] = {};              // gemv timing ring (whole GEMV, or its first panel)
     hipEvent_t ev_g2[kLag] = {}, ev_g3[kLag] = {};              // second panel of a split GEMV
     bool split_slot[kLag] = {};
+    bool timed_slot[kLag] = {};                                 // the slot's iteration recorded its timing events
 };
 
 }  // namespace
@@ -117,6 +121,25 @@ struct lam_hip_ctx {
     int64_t opt_finalize = 1;      // several shards: 1 = producer kernels reduce their partials themselves (Finalize);
                                    // 0 = separate 1-block finalize_sum_kernel launches (A/B measurements)
     uint64_t n_collectives = 0;    // RCCL calls enqueued by this context (diagnostics: must match across ranks)
+    int64_t opt_gemv_timing = 8;   // HIP-event pair around the GEMV of every T-th iteration (t_gemv of the stats); 0 = never.
+                                   // Every record is a marker packet between the kernels: timing every iteration costs 8 us
+                                   // per iteration (profiles/r03_event_cost.txt)
+    // One process, several shards: how the host orders the shards' streams (profiles/r03_host_enqueue_cost.txt).  Every
+    // cross-stream event operation costs the host 3-5 us, so the event-based forms all stay above 0.2 ms per iteration
+    // at P = 8; the form that does not (no events at all) is the in-kernel flag exchange, option "exchange" = 2.
+    int64_t opt_host_threads = 0;  // 1 = every shard is enqueued by a host thread of its own (the reference's shape)
+    int64_t opt_hub = 0;           // 1 = the shards' streams meet at ONE join event per exchange (P waits on a hub stream +
+                                   // P waits on its event: 3(3P+1) calls per iteration) instead of every stream waiting
+                                   // for every other one (3P^2 calls); fewer host calls, one more event hop on the device
+    hipStream_t hub_stream = nullptr;          // on shard 0's device
+    hipEvent_t ev_join[3] = {};                // p.Ap partials posted / r.r partials posted / p slices stored
+    int64_t opt_assume_cus = 0;    // testing: pretend the device has this many CUs when checking that a launch whose
+                                   // workgroups wait for each other is fully resident (0 = ask the device)
+    bool fuse_active = false;      // the current CG state uses update_fused_kernel (decided in cg_init: option + residency)
+    // runtime calls issued by the iteration loop (diagnostics: host cost of an iteration, tools/host_enqueue_cost.py)
+    std::atomic<uint64_t> n_launch{0}, n_record{0}, n_wait{0}, n_setdev{0};
+    uint64_t enqueue_ns = 0;       // host time spent issuing iterations (the waits for the device's progress excluded)
+    std::mutex err_mu;             // `err` may be written by the per-shard enqueue threads
     // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
     Mail *mail = nullptr;                       // own mailbox, fine-grained device memory
     bool mail_coarse = false;                   // ... or ordinary device memory (enough for one shard, not for peers)
@@ -129,7 +152,7 @@ struct lam_hip_ctx {
     bool direct_ok = false;
     bool cg_direct = false;                     // the current CG state runs on the direct exchange
     uint32_t epoch = 0;                         // bumped by every cg_init: mailbox tags never repeat
-    int *direct_err = nullptr;                  // pinned host: a bounded wait of the direct exchange expired
+    int *direct_err = nullptr;                  // pinned host: a bounded in-kernel wait expired ([0] = which, see cg_iterate)
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
@@ -162,7 +185,8 @@ int fail(lam_hip_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
+    if (c) { std::lock_guard<std::mutex> lk(c->err_mu); c->err = buf; }
+    else g_create_error = buf;
     return code;
 }
 
@@ -188,6 +212,23 @@ int fail(lam_hip_ctx *c, int code, const char *fmt, ...)
         if (rc_ != 0) return rc_;    \
     } while (0)
 
+// the iteration loop's runtime calls, counted (option "hip_calls_*"): what an iteration costs the host
+#define LAUNCHED(c)                                  \
+    do {                                             \
+        (c)->n_launch++;                             \
+        HIPCHK((c), hipGetLastError());              \
+    } while (0)
+#define RECORD(c, ev, st)                            \
+    do {                                             \
+        (c)->n_record++;                             \
+        HIPCHK((c), hipEventRecord((ev), (st)));     \
+    } while (0)
+#define WAITEV(c, st, ev)                            \
+    do {                                             \
+        (c)->n_wait++;                               \
+        HIPCHK((c), hipStreamWaitEvent((st), (ev), 0)); \
+    } while (0)
+
 void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
 {
     // ConjugateGradient_CPU_MPI_OMP.hpp:176-184: n/P rows each, the remainder on the LAST rank
@@ -196,15 +237,25 @@ void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
     *nrows = base + ((q == P - 1) ? n % (uint64_t)P : 0);
 }
 
-// File descriptor 1 points at stderr while at least one of these exists.  Counted under a lock: contexts may be
-// created from several threads at once (the ranks-as-threads test double), and the first one in must be the one
-// that remembers the real stdout, the last one out the one that restores it.
+// OPT-IN (environment LAM_HIP_QUIET_RCCL=1, set by this package's drivers, whose stdout is a one-line protocol): file
+// descriptor 1 points at stderr while at least one of these exists, i.e. for the duration of ncclCommInitRank, which
+// prints a version banner to stdout.  A library must not move a host application's stdout around by default, so
+// without the variable nothing is touched.  Counted under a lock: contexts may be created from several threads at
+// once (the ranks-as-threads test double), and the first one in must be the one that remembers the real stdout, the
+// last one out the one that restores it.
 struct StdoutToStderr {
+    static bool wanted()
+    {
+        const char *q = getenv("LAM_HIP_QUIET_RCCL");
+        return q && *q && strcmp(q, "0") != 0;
+    }
+    const bool on = wanted();
     static std::mutex &mu() { static std::mutex m; return m; }
     static int &depth() { static int d = 0; return d; }
     static int &saved() { static int fd = -1; return fd; }
     StdoutToStderr()
     {
+        if (!on) return;
         std::lock_guard<std::mutex> lk(mu());
         if (depth()++ == 0) {
             fflush(stdout);
@@ -214,6 +265,7 @@ struct StdoutToStderr {
     }
     ~StdoutToStderr()
     {
+        if (!on) return;
         std::lock_guard<std::mutex> lk(mu());
         if (--depth() == 0 && saved() >= 0) {
             fflush(stdout);
@@ -349,6 +401,7 @@ struct Impl {
             hipLaunchKernelGGL((symv_reduce_kernel<TA>), dim3(nblk), dim3(kBlock), 0, s.stream, (const TA *)s.symv_rowpart,
                                (const TA *)s.symv_colpart, (const TA *)p, (TA *)y, partial, n, ntiles, sc);
             HIPCHK(c, hipGetLastError());
+            c->n_launch += 2;
             return 0;
         } else {
             return fail(c, LAM_HIP_EINVAL, "the symmetric product needs matrix and vector of one type");
@@ -372,7 +425,7 @@ struct Impl {
         GemvArgs<TA, TV> a;
         a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
         if (fin != nullptr && partial != nullptr) a.fin = *fin;
-        else { a.fin.active = 0; a.fin.mail = 0; a.fin.seq = 0; a.fin.dst.n = 0; a.fin.slot = 0; }
+        else { a.fin.active = 0; a.fin.mail = 0; a.fin.seq = 0; a.fin.dst.n = 0; a.fin.slot = 0; a.fin.host_err = c->direct_err; }
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
         a.seg_begin[0] = 0; a.seg_end[0] = c->n; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
         if (panel == 1) { a.seg_begin[0] = lo; a.seg_end[0] = hi; }
@@ -422,7 +475,7 @@ struct Impl {
         } else {
             hipLaunchKernelGGL((gemv_generic_kernel<TA, TV>), dim3(grid), dim3(kBlock), 0, s.stream, a);
         }
-        HIPCHK(c, hipGetLastError());
+        LAUNCHED(c);
         return 0;
     }
 };
@@ -454,6 +507,7 @@ int dispatch(lam_hip_ctx *c, F &&f)
 
 int set_dev(lam_hip_ctx *c, const ShardBase &s)
 {
+    c->n_setdev++;
     HIPCHK(c, hipSetDevice(s.dev));
     // hipGetLastError() is only used to pick up launch failures right after a launch; drop whatever an
     // earlier, already reported failure (possibly of another context) left in the thread's error slot
@@ -507,11 +561,26 @@ void release_handles(ShardBase &s)
     hipEvent_t *evs[] = {&s.ev_a, &s.ev_b, &s.ev_p, &s.ev_gathered};
     for (auto e : evs) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     for (int i = 0; i < kLag; i++) {
-        hipEvent_t *ring[] = {&s.ev_lag[i], &s.ev_g0[i], &s.ev_g1[i], &s.ev_g2[i], &s.ev_g3[i]};
+        hipEvent_t *ring[] = {&s.ev_g0[i], &s.ev_g1[i], &s.ev_g2[i], &s.ev_g3[i]};
         for (auto e : ring) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     }
     if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); s.comm_stream = nullptr; }
     if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
+}
+
+// a context whose creation failed half-way: give back what it already holds
+void release_hub(lam_hip_ctx *c)
+{
+    if (c->sh.empty() || hipSetDevice(c->sh[0].dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (auto &ev : c->ev_join) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (c->hub_stream) { (void)hipStreamSynchronize(c->hub_stream); (void)hipStreamDestroy(c->hub_stream); c->hub_stream = nullptr; }
+}
+
+void abandon(lam_hip_ctx *c)
+{
+    release_hub(c);
+    for (auto &s : c->sh) { free_shard(s); release_handles(s); }
+    if (c->direct_err) { (void)hipHostFree(c->direct_err); c->direct_err = nullptr; }
 }
 
 int create_common(lam_hip_ctx *c)
@@ -539,12 +608,23 @@ int create_common(lam_hip_ctx *c)
             if (hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
         for (int i = 0; i < kLag; i++) {
-            if (hipEventCreateWithFlags(&s.ev_lag[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreate(&s.ev_g0[i]) != hipSuccess || hipEventCreate(&s.ev_g1[i]) != hipSuccess ||
+            if (hipEventCreate(&s.ev_g0[i]) != hipSuccess || hipEventCreate(&s.ev_g1[i]) != hipSuccess ||
                 hipEventCreate(&s.ev_g2[i]) != hipSuccess || hipEventCreate(&s.ev_g3[i]) != hipSuccess)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
         }
     }
+    // hub of the one-process exchange (see hub_join): a stream on shard 0's device and one join event per exchange
+    if (!c->rank_mode && c->sh.size() > 1) {
+        if (hipSetDevice(c->sh[0].dev) != hipSuccess || hipStreamCreateWithFlags(&c->hub_stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(nullptr, LAM_HIP_EHIP, "hipStreamCreate (hub) failed");
+        for (auto &ev : c->ev_join)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventReleaseToSystem) != hipSuccess)
+                return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
+    }
+    // the error word of the bounded in-kernel waits (reducer workgroups, fused update, direct exchange)
+    if (hipSetDevice(c->sh[0].dev) != hipSuccess || hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault) != hipSuccess)
+        return fail(nullptr, LAM_HIP_EHIP, "hipHostMalloc (error word) failed");
+    memset(c->direct_err, 0, 64);
     // peer access between distinct devices of one process (direct xGMI stores)
     for (auto &s : c->sh)
         for (auto &t : c->sh)
@@ -586,15 +666,23 @@ int sync_all(lam_hip_ctx *c)
 // symmetric product's second pass writes plain per-workgroup partials of p.Ap: its consumer sums them.
 bool producer_reduces(const lam_hip_ctx *c, bool second) { return c->opt_finalize != 0 && (second || !c->symv_active()); }
 
-// Where the reduced partial of shard `s` goes (see lam_kernels.h, Finalize): slot `index` of the
-// gather array of every local shard (one process: peer stores) or of this rank (rank mode).
-Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
+Finalize no_finalize(const lam_hip_ctx *c)
 {
     Finalize f;
     f.active = 0;
     f.mail = 0;
     f.seq = 0;
     f.dst.n = 0;
+    f.slot = 0;
+    f.host_err = c ? c->direct_err : nullptr;
+    return f;
+}
+
+// Where the reduced partial of shard `s` goes (see lam_kernels.h, Finalize): slot `index` of the
+// gather array of every local shard (one process: peer stores) or of this rank (rank mode).
+Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
+{
+    Finalize f = no_finalize(c);
     f.slot = s.index;
     if (c->rank_mode) { f.dst.n = 1; f.dst.p[0] = second ? s.gather_b : s.gather_a; }
     else {
@@ -615,35 +703,69 @@ Finalize make_finalize(lam_hip_ctx *c, ShardBase &s, bool second)
 //   rank mode          : in-place ncclAllGather of the 8-byte partials (slot = rank)
 // `finalized` = the producer kernel already reduced its partials (Finalize); otherwise a 1-block
 // finalize_sum_kernel does it here (cg_init, and option "finalize" = 0).
+// Two halves per shard, so that every shard can be driven by a host thread of its own: reduce_post is what the
+// PRODUCING shard puts on its stream behind the producer kernel, reduce_wait makes a CONSUMING shard's stream wait
+// for its peers' posts -- which must all have been issued by then (single thread: post for all shards, then wait
+// for all; threads: a host barrier in between).  The shard's device is current in both.
+int reduce_post(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, bool check_stop, bool finalized)
+{
+    if (!c->rank_mode && c->total_shards == 1) return 0;
+    if (!finalized) {
+        Finalize f = make_finalize(c, s, second);
+        const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
+        const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
+        hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, f.dst, f.slot,
+                           check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
+        LAUNCHED(c);
+    }
+    if (c->rank_mode) {
+        double *buf = second ? s.gather_b : s.gather_a;
+        NCCLCHK(c, ncclAllGather(buf + c->rank, buf, 1, ncclDouble, c->comm, s.stream));
+        c->n_collectives++;
+    } else {
+        RECORD(c, second ? s.ev_b : s.ev_a, s.stream);
+    }
+    return 0;
+}
+
+// Is the all-to-all ordering between the shards' streams done through the hub?
+bool hub_active(const lam_hip_ctx *c) { return !c->rank_mode && c->total_shards > 2 && c->opt_hub != 0 && c->hub_stream != nullptr; }
+
+// One process, several shards: after every shard has posted exchange `which` (0 = p.Ap partials, 1 = r.r partials,
+// 2 = p slices), the hub stream waits for the P posts and records ONE join event; every shard then waits for that
+// event -- 2P + 1 runtime calls where the all-to-all form needs P(P-1) (P = 8: 17 instead of 56).  The join adds
+// one event hop on the device; every stream still depends on every post (the hub's wait list is all of them), and the
+// events carry the same system-scope release / acquire as before.
+int hub_join(lam_hip_ctx *c, int which)
+{
+    if (!hub_active(c)) return 0;
+    LAMCHK(set_dev(c, c->sh[0]));
+    for (auto &t : c->sh) WAITEV(c, c->hub_stream, which == 0 ? t.ev_a : (which == 1 ? t.ev_b : t.ev_p));
+    RECORD(c, c->ev_join[which], c->hub_stream);
+    return 0;
+}
+
+int reduce_wait(lam_hip_ctx *c, ShardBase &s, bool second)
+{
+    if (c->rank_mode || c->total_shards == 1) return 0;
+    if (hub_active(c)) { WAITEV(c, s.stream, c->ev_join[second ? 1 : 0]); return 0; }
+    for (auto &t : c->sh)
+        if (&t != &s) WAITEV(c, s.stream, second ? t.ev_b : t.ev_a);
+    return 0;
+}
+
+// both halves for all shards from one thread (cg_init)
 int reduce_step(lam_hip_ctx *c, bool second, bool use_gemv_part, bool check_stop, bool finalized)
 {
-    const int L = (int)c->sh.size();
     if (!c->rank_mode && c->total_shards == 1) return 0;
-    for (int q = 0; q < L; q++) {
-        ShardBase &s = c->sh[q];
+    for (auto &s : c->sh) {
         LAMCHK(set_dev(c, s));
-        if (!finalized) {
-            Finalize f = make_finalize(c, s, second);
-            const double *src = use_gemv_part ? s.part_gemv : s.part_vec;
-            const int nsrc = use_gemv_part ? s.gemv_blocks : s.vec_blocks;
-            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, src, nsrc, f.dst, f.slot,
-                               check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
-            HIPCHK(c, hipGetLastError());
-        }
-        if (c->rank_mode) {
-            double *buf = second ? s.gather_b : s.gather_a;
-            NCCLCHK(c, ncclAllGather(buf + c->rank, buf, 1, ncclDouble, c->comm, s.stream));
-            c->n_collectives++;
-        } else {
-            HIPCHK(c, hipEventRecord(second ? s.ev_b : s.ev_a, s.stream));
-        }
+        LAMCHK(reduce_post(c, s, second, use_gemv_part, check_stop, finalized));
     }
-    if (c->rank_mode) return 0;
-    for (int q = 0; q < L; q++) {
-        ShardBase &s = c->sh[q];
+    LAMCHK(hub_join(c, second ? 1 : 0));
+    for (auto &s : c->sh) {
         LAMCHK(set_dev(c, s));
-        for (int t = 0; t < L; t++)
-            if (t != q) HIPCHK(c, hipStreamWaitEvent(s.stream, second ? c->sh[t].ev_b : c->sh[t].ev_a, 0));
+        LAMCHK(reduce_wait(c, s, second));
     }
     return 0;
 }
@@ -659,61 +781,78 @@ void red_source(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, b
     }
 }
 
-// make every replica of p complete after the slices were stored
-int gather_p_step(lam_hip_ctx *c)
+// rank mode: make this rank's replica of p complete after the slices were stored (RCCL all-gather)
+int gather_p_rank(lam_hip_ctx *c)
 {
-    const int L = (int)c->sh.size();
-    if (!c->rank_mode && c->total_shards == 1) return 0;
-    if (c->rank_mode) {
-        ShardBase &s = c->sh[0];
-        const uint64_t base = c->n / (uint64_t)c->nranks;
-        const size_t ev = c->esz_v();
-        const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
-        // The all-gather runs on its own stream so that the next GEMV's own-slice panel overlaps it;
-        // the two streams are tied by events, so operations on the communicator stay totally ordered
-        // (every other collective is enqueued on s.stream after a wait on ev_gathered).
-        hipStream_t cs = c->opt_overlap ? s.comm_stream : s.stream;
-        if (c->opt_overlap) {
-            HIPCHK(c, hipEventRecord(s.ev_p, s.stream));
-            HIPCHK(c, hipStreamWaitEvent(cs, s.ev_p, 0));
+    ShardBase &s = c->sh[0];
+    const uint64_t base = c->n / (uint64_t)c->nranks;
+    const size_t ev = c->esz_v();
+    const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
+    // The all-gather runs on its own stream so that the next GEMV's own-slice panel overlaps it;
+    // the two streams are tied by events, so operations on the communicator stay totally ordered
+    // (every other collective is enqueued on s.stream after a wait on ev_gathered).
+    hipStream_t cs = c->opt_overlap ? s.comm_stream : s.stream;
+    if (c->opt_overlap) {
+        RECORD(c, s.ev_p, s.stream);
+        WAITEV(c, cs, s.ev_p);
+    }
+    struct Done {   // record ev_gathered on every exit path below
+        lam_hip_ctx *c; ShardBase &s; hipStream_t cs;
+        int finish() {
+            if (!c->opt_overlap) return 0;
+            RECORD(c, s.ev_gathered, cs);
+            c->gather_pending = true;
+            return 0;
         }
-        struct Done {   // record ev_gathered on every exit path below
-            lam_hip_ctx *c; ShardBase &s; hipStream_t cs;
-            int finish() {
-                if (!c->opt_overlap) return 0;
-                HIPCHK(c, hipEventRecord(s.ev_gathered, cs));
-                c->gather_pending = true;
-                return 0;
-            }
-        } done{c, s, cs};
-        if (c->n % (uint64_t)c->nranks == 0) {
-            NCCLCHK(c, ncclAllGather((const char *)s.p + s.row0 * ev, s.p, base, dt, c->comm, cs));
-            c->n_collectives++;
-            return done.finish();
-        } else {
-            // uneven last block (reference: MPI_Allgatherv): one broadcast per owner
-            NCCLCHK(c, ncclGroupStart());
-            for (int q = 0; q < c->nranks; q++) {
-                uint64_t r0, nr;
-                partition(c->n, c->nranks, q, &r0, &nr);
-                char *ptr = (char *)s.p + r0 * ev;
-                NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, cs));
-                c->n_collectives++;
-            }
-            NCCLCHK(c, ncclGroupEnd());
-        }
+    } done{c, s, cs};
+    if (c->n % (uint64_t)c->nranks == 0) {
+        NCCLCHK(c, ncclAllGather((const char *)s.p + s.row0 * ev, s.p, base, dt, c->comm, cs));
+        c->n_collectives++;
         return done.finish();
     }
-    for (int q = 0; q < L; q++) {
-        ShardBase &s = c->sh[q];
-        LAMCHK(set_dev(c, s));
-        HIPCHK(c, hipEventRecord(s.ev_p, s.stream));
+    // uneven last block (reference: MPI_Allgatherv): one broadcast per owner
+    NCCLCHK(c, ncclGroupStart());
+    for (int q = 0; q < c->nranks; q++) {
+        uint64_t r0, nr;
+        partition(c->n, c->nranks, q, &r0, &nr);
+        char *ptr = (char *)s.p + r0 * ev;
+        NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, cs));
+        c->n_collectives++;
     }
-    for (int q = 0; q < L; q++) {
-        ShardBase &s = c->sh[q];
+    NCCLCHK(c, ncclGroupEnd());
+    return done.finish();
+}
+
+// one process, several shards: the slices were stored straight into every replica (peer stores); events order the
+// next reader of a replica behind all of its writers.  Halves as for reduce_post / reduce_wait.
+int gather_post(lam_hip_ctx *c, ShardBase &s)
+{
+    if (c->rank_mode || c->total_shards == 1) return 0;
+    RECORD(c, s.ev_p, s.stream);
+    return 0;
+}
+int gather_wait(lam_hip_ctx *c, ShardBase &s)
+{
+    if (c->rank_mode || c->total_shards == 1) return 0;
+    if (hub_active(c)) { WAITEV(c, s.stream, c->ev_join[2]); return 0; }
+    for (auto &t : c->sh)
+        if (&t != &s) WAITEV(c, s.stream, t.ev_p);
+    return 0;
+}
+
+// make every replica of p complete after the slices were stored (all shards, one thread: cg_init)
+int gather_p_step(lam_hip_ctx *c)
+{
+    if (!c->rank_mode && c->total_shards == 1) return 0;
+    if (c->rank_mode) return gather_p_rank(c);
+    for (auto &s : c->sh) {
         LAMCHK(set_dev(c, s));
-        for (int t = 0; t < L; t++)
-            if (t != q) HIPCHK(c, hipStreamWaitEvent(s.stream, c->sh[t].ev_p, 0));
+        LAMCHK(gather_post(c, s));
+    }
+    LAMCHK(hub_join(c, 2));
+    for (auto &s : c->sh) {
+        LAMCHK(set_dev(c, s));
+        LAMCHK(gather_wait(c, s));
     }
     return 0;
 }
@@ -773,10 +912,6 @@ int ensure_mail(lam_hip_ctx *c, bool *got_finegrained)
     if (c->bcast == nullptr) {
         HIPCHK(c, hipMalloc((void **)&c->bcast, 2 * kBcastLines * sizeof(BcastLine)));
         HIPCHK(c, hipMemset(c->bcast, 0, 2 * kBcastLines * sizeof(BcastLine)));
-    }
-    if (c->direct_err == nullptr) {
-        HIPCHK(c, hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault));
-        memset(c->direct_err, 0, 64);
     }
     return 0;
 }
@@ -868,6 +1003,33 @@ int setup_direct(lam_hip_ctx *c)
     return 0;
 }
 
+// Is the GEMV of iteration k timed (HIP-event pair on the launch stream, shard 0 only)?  Option "gemv_timing" = T
+// times every T-th iteration; each record is a marker packet between the iteration's kernels, so T > 1 keeps most
+// iterations free of them.
+bool timed_iteration(const lam_hip_ctx *c, const ShardBase &s, int k)
+{
+    return &s == &c->sh[0] && c->opt_gemv_timing > 0 && (k - 1) % c->opt_gemv_timing == 0;
+}
+
+// Can a launch of `blocks` workgroups of update_fused_kernel be resident all at once?  Its workgroups wait for each
+// other inside the launch (compute workgroups for the reducer's broadcast, the reducer for their partials), so a
+// workgroup that cannot start until another one exits would hold everybody until the bounded waits expire.  256-thread
+// workgroups are admitted per CU up to min(occupancy API, 8) (MI355X_MICROARCH.md, residency); a CU mask or a
+// partitioned device that the runtime reports shows up in the CU count.  What the query cannot see (other kernels on
+// the device) is still caught by the bounded waits, which end in an error, never in a hang or a silent NaN.
+template <typename TV>
+bool fused_launch_resident(lam_hip_ctx *c, const ShardBase &s, int blocks)
+{
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, update_fused_kernel<TV>, kBlock, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (c->opt_assume_cus > 0) cus = (int)c->opt_assume_cus;
+    return (int64_t)std::min(per_cu, 8) * (int64_t)cus >= (int64_t)blocks;
+}
+
 int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
     return dispatch(c, [&](auto impl) -> int {
@@ -885,7 +1047,7 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         // option "overlap" = 0: no own-slice panel -- wait for the flags first, then one GEMV launch (the split
         // costs ~8 us of launch and ramp; it pays when the slices arrive later than that)
         if (P > 1 && c->opt_overlap && (!I::fast_ok(c) || (a % I::VEC == 0 && b % I::VEC == 0))) { lo = a; hi = b; }
-        Finalize fa;
+        Finalize fa = no_finalize(c);
         fa.active = 1; fa.mail = 1; fa.seq = seq; fa.slot = 0; fa.dst.n = P;
         for (int q = 0; q < P; q++) fa.dst.p[q] = &c->peer_mail[q]->pap[c->rank];
         BlockCounts nb;
@@ -896,30 +1058,32 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         }
         // the fused update launch of iteration k-1 may have waited for the slices already (its waiter workgroup)
         const bool need_wait = P > 1 && k > 1 && c->waited_k != k - 1;
+        const bool timed = timed_iteration(c, s, k);
         s.split_slot[slot] = hi > lo;
+        s.timed_slot[slot] = timed;
         if (hi > lo) {
-            HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+            if (timed) RECORD(c, s.ev_g0[slot], s.stream);
             LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, s.sc, 1, lo, hi));
-            HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+            if (timed) RECORD(c, s.ev_g1[slot], s.stream);
         }
         if (need_wait) {
             hipLaunchKernelGGL(wait_p_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const Mail *)c->mail, P, c->rank, nb, seq - 1,
                                (const CgScalars *)s.sc, c->direct_err);
-            HIPCHK(c, hipGetLastError());
+            LAUNCHED(c);
         }
         if (hi > lo) {
-            HIPCHK(c, hipEventRecord(s.ev_g2[slot], s.stream));
+            if (timed) RECORD(c, s.ev_g2[slot], s.stream);
             LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi, &fa));
-            HIPCHK(c, hipEventRecord(s.ev_g3[slot], s.stream));
+            if (timed) RECORD(c, s.ev_g3[slot], s.stream);
         } else {
-            HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+            if (timed) RECORD(c, s.ev_g0[slot], s.stream);
             LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 0, 0, 0, &fa));
-            HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+            if (timed) RECORD(c, s.ev_g1[slot], s.stream);
         }
         // 2. x, r: waits in the kernel for the P partials of p.Ap; its reducer posts the r.r partial
         Finalize fb = fa;
         for (int q = 0; q < P; q++) fb.dst.p[q] = &c->peer_mail[q]->rr[c->rank];
-        if (c->opt_fuse) {
+        if (c->fuse_active) {
             // steps 2 and 3 in ONE launch; without an own-slice panel (overlap 0) a waiter workgroup also holds the
             // launch open until the peers' slices for the next GEMV are in: 2 launches per iteration
             PtrList plf;
@@ -936,14 +1100,14 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
                                (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fb, MailWait{c->mail->pap, P, seq, c->direct_err},
                                MailWait{c->mail->rr, P, seq, c->direct_err}, c->bcast, plf, s.row0, (volatile int *)s.host_flags, postf,
                                (const Mail *)c->mail, nb);
-            HIPCHK(c, hipGetLastError());
+            LAUNCHED(c);
             if (waiter) c->waited_k = k;
             return 0;
         }
         hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
                            (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
                            MailWait{c->mail->pap, P, seq, c->direct_err});
-        HIPCHK(c, hipGetLastError());
+        LAUNCHED(c);
         // 3. stop test + p slice into every replica + flags
         PtrList pl;
         pl.n = P;
@@ -959,7 +1123,7 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
                            rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows, (volatile int *)s.host_flags,
                            MailWait{c->mail->rr, P, seq, c->direct_err}, post);
-        HIPCHK(c, hipGetLastError());
+        LAUNCHED(c);
         return 0;
     });
 }
@@ -999,17 +1163,19 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         char *rec = (char *)s.ap_gather + (uint64_t)c->rank * stride;
         // 1. GEMV straight into this rank's record; its last workgroup leaves the rank's p.Ap partial
         //    behind the slice (with option "finalize" = 0: a 1-block launch does)
-        Finalize f;
+        Finalize f = no_finalize(c);
         f.active = c->opt_finalize ? 1 : 0;
-        f.mail = 0; f.seq = 0;
         f.dst.n = 1; f.dst.p[0] = rec + base * sizeof(TV); f.slot = 0;
-        HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
+        const bool timed = timed_iteration(c, s, k);
+        s.split_slot[slot] = false;
+        s.timed_slot[slot] = timed;
+        if (timed) RECORD(c, s.ev_g0[slot], s.stream);
         LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc, 0, 0, 0, &f));
-        HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
+        if (timed) RECORD(c, s.ev_g1[slot], s.stream);
         if (!c->opt_finalize) {
             hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, s.gemv_blocks,
                                f.dst, 0, (const CgScalars *)s.sc);
-            HIPCHK(c, hipGetLastError());
+            LAUNCHED(c);
         }
         // 2. the iteration's only collective
         NCCLCHK(c, ncclAllGather(rec, s.ap_gather, stride, ncclChar, c->comm, s.stream));
@@ -1018,11 +1184,11 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         const int grid = vec_grid(c->n);
         hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
                            base, c->nranks, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
-        HIPCHK(c, hipGetLastError());
+        LAUNCHED(c);
         // 4. beta, stop test, FULL p
         hipLaunchKernelGGL((update_p_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc,
                            k, rel_error, (const TV *)s.r_full, (TV *)s.p, c->n, (volatile int *)s.host_flags);
-        HIPCHK(c, hipGetLastError());
+        LAUNCHED(c);
         return 0;
     });
 }
@@ -1038,7 +1204,18 @@ int do_cg_init(lam_hip_ctx *c)
         LAMCHK(setup_direct(c));
         c->cg_direct = c->direct_ok;
     }
-    if (!c->rank_mode && c->total_shards == 1 && c->opt_fuse && c->opt_finalize) LAMCHK(ensure_mail(c, nullptr));
+    // The fused vector step (one shard; the direct exchange) is a launch whose workgroups wait for each other: used
+    // only when the whole grid (compute workgroups + reducer + waiter) can be resident at once, else the two-kernel form.
+    c->fuse_active = false;
+    if (c->opt_fuse && c->opt_finalize && (c->cg_direct || (!c->rank_mode && c->total_shards == 1))) {
+        ShardBase &s0 = c->sh[0];
+        LAMCHK(set_dev(c, s0));
+        c->fuse_active = dispatch(c, [&](auto impl) -> int {
+            using TV = typename ImplTraits<decltype(impl)>::TV;
+            return fused_launch_resident<TV>(c, s0, s0.vec_blocks + 2) ? 1 : 0;
+        }) == 1;
+    }
+    if (c->fuse_active && !c->cg_direct) LAMCHK(ensure_mail(c, nullptr));
     if (c->exchange1_ok()) return do_cg_init_exchange1(c);
     c->cg_exchange1 = false;
     return dispatch(c, [&](auto impl) -> int {
@@ -1066,92 +1243,187 @@ int do_cg_init(lam_hip_ctx *c)
     });
 }
 
+// ---- the general iteration, one shard at a time -------------------------------------------------------------------
+// Four phases per shard; between two phases every shard must have ISSUED the previous one (its event records are
+// what the next phase's stream waits refer to).  One host thread: phase by phase over all shards.  One host thread
+// per shard (option "host_threads", the shape of the reference's OpenMP-thread-per-device loop,
+// ConjugateGradient_MultiGPUS_CUDA.cu:337-378): a host barrier between the phases (iterate_threaded).
+//   A  GEMV (+ partial p.Ap) and its post             B  wait for the peers' p.Ap; x, r update (+ partial r.r); post
+//   C  wait for the peers' r.r; stop test + p update into every replica; post        D  wait for the peers' p slices
+template <typename I>
+int phase_gemv(lam_hip_ctx *c, ShardBase &s, int k, int slot)
+{
+    using TV = typename ImplTraits<I>::TV;
+    // With an own-slice panel: that panel first (it only needs the p slice this shard wrote itself), then wait for
+    // the all-gather, then the remaining columns.
+    uint64_t lo, hi;
+    cg_panel<I>(c, s, &lo, &hi);
+    const bool timed = timed_iteration(c, s, k);
+    s.timed_slot[slot] = timed;
+    const bool fin_a = producer_reduces(c, false);
+    if (c->symv_active()) {
+        s.split_slot[slot] = false;
+        if (timed) RECORD(c, s.ev_g0[slot], s.stream);
+        LAMCHK(I::launch_symv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
+        if (timed) RECORD(c, s.ev_g1[slot], s.stream);
+        return reduce_post(c, s, false, true, true, fin_a);
+    }
+    s.split_slot[slot] = hi > lo;
+    const Finalize fa = make_finalize(c, s, false);
+    if (hi > lo) {
+        // the two panels are timed separately so that t_gemv is kernel time, not the wait in between
+        if (timed) RECORD(c, s.ev_g0[slot], s.stream);
+        LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, s.sc, 1, lo, hi));
+        if (timed) RECORD(c, s.ev_g1[slot], s.stream);
+        if (c->gather_pending) WAITEV(c, s.stream, s.ev_gathered);
+        if (timed) RECORD(c, s.ev_g2[slot], s.stream);
+        LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi, &fa));
+        if (timed) RECORD(c, s.ev_g3[slot], s.stream);
+    } else {
+        if (c->gather_pending) WAITEV(c, s.stream, s.ev_gathered);
+        if (timed) RECORD(c, s.ev_g0[slot], s.stream);
+        LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 0, 0, 0, &fa));
+        if (timed) RECORD(c, s.ev_g1[slot], s.stream);
+    }
+    return reduce_post(c, s, false, true, true, fin_a);
+}
+
+template <typename I>
+int phase_xr(lam_hip_ctx *c, ShardBase &s, int k, double rel_error)
+{
+    using TV = typename ImplTraits<I>::TV;
+    const bool fin_a = producer_reduces(c, false), fin_b = producer_reduces(c, true);
+    LAMCHK(reduce_wait(c, s, false));
+    const double *red; int nred;
+    red_source(c, s, false, true, fin_a, &red, &nred);
+    if (c->fuse_active) {
+        // one shard: phases B and C in ONE launch; the r.r total travels through the context's own mailbox
+        const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
+        Finalize fr = no_finalize(c);
+        fr.active = 1; fr.seq = seq;                 // one shard: the total goes straight to the broadcast slot
+        BlockCounts nb;
+        for (auto &v : nb.n) v = 0;
+        hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, red, nred, s.sc, k, rel_error,
+                           (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fr,
+                           MailWait{nullptr, 0, 0, nullptr}, MailWait{c->mail->rr, 1, seq, c->direct_err}, c->bcast, plist_p(c), s.row0,
+                           (volatile int *)s.host_flags, no_post(), (const Mail *)c->mail, nb);
+        LAUNCHED(c);
+        return 0;
+    }
+    const Finalize fb = make_finalize(c, s, true);
+    hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + (fb.active ? 1 : 0)), dim3(kBlock), 0, s.stream, red, nred,
+                       s.sc, k, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
+                       MailWait{nullptr, 0, 0, nullptr});
+    LAUNCHED(c);
+    return reduce_post(c, s, true, false, true, fin_b);
+}
+
+template <typename I>
+int phase_p(lam_hip_ctx *c, ShardBase &s, int k, double rel_error)
+{
+    using TV = typename ImplTraits<I>::TV;
+    if (c->fuse_active) return 0;
+    const bool fin_b = producer_reduces(c, true);
+    LAMCHK(reduce_wait(c, s, true));
+    const double *red; int nred;
+    red_source(c, s, true, false, fin_b, &red, &nred);
+    hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
+                       rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, plist_p(c), s.row0, s.nrows,
+                       (volatile int *)s.host_flags, MailWait{nullptr, 0, 0, nullptr}, no_post());
+    LAUNCHED(c);
+    return gather_post(c, s);
+}
+
 int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
     if (c->cg_direct) return enqueue_iteration_direct(c, k, rel_error, slot);
     if (c->cg_exchange1) return enqueue_iteration_exchange1(c, k, rel_error, slot);
     return dispatch(c, [&](auto impl) -> int {
         using I = decltype(impl);
-        using TV = typename ImplTraits<I>::TV;
-        // 1. GEMV + partial p.Ap.  With an own-slice panel: that panel first (it only needs the p slice
-        //    this shard wrote itself), then wait for the all-gather, then the remaining columns.
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
-            uint64_t lo, hi;
-            cg_panel<I>(c, s, &lo, &hi);
-            if (c->symv_active()) {
-                s.split_slot[slot] = false;
-                HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
-                LAMCHK(I::launch_symv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc));
-                HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
-                continue;
-            }
-            s.split_slot[slot] = hi > lo;
-            const Finalize fa = make_finalize(c, s, false);
-            if (hi > lo) {
-                // the two panels are timed separately so that t_gemv is kernel time, not the wait in between
-                HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
-                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, nullptr, s.sc, 1, lo, hi));
-                HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
-                if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
-                HIPCHK(c, hipEventRecord(s.ev_g2[slot], s.stream));
-                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 2, lo, hi, &fa));
-                HIPCHK(c, hipEventRecord(s.ev_g3[slot], s.stream));
-            } else {
-                if (c->gather_pending) HIPCHK(c, hipStreamWaitEvent(s.stream, s.ev_gathered, 0));
-                HIPCHK(c, hipEventRecord(s.ev_g0[slot], s.stream));
-                LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)s.Ap, s.part_gemv, s.sc, 0, 0, 0, &fa));
-                HIPCHK(c, hipEventRecord(s.ev_g1[slot], s.stream));
-            }
+            LAMCHK(phase_gemv<I>(c, s, k, slot));
         }
         c->gather_pending = false;
-        const bool fin_a = producer_reduces(c, false), fin_b = producer_reduces(c, true);
-        LAMCHK(reduce_step(c, false, true, true, fin_a));
-        if (!c->rank_mode && c->total_shards == 1 && c->opt_fuse && c->opt_finalize && c->mail != nullptr) {
-            // one shard: steps 2 and 3 in ONE launch; the r.r total travels through the context's own mailbox
-            ShardBase &s = c->sh[0];
-            LAMCHK(set_dev(c, s));
-            const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
-            const double *red; int nred;
-            red_source(c, s, false, true, fin_a, &red, &nred);
-            Finalize fr;
-            fr.active = 1; fr.mail = 0; fr.seq = seq; fr.slot = 0; fr.dst.n = 0;      // one shard: the total goes straight to the broadcast slot
-            BlockCounts nb;
-            for (auto &v : nb.n) v = 0;
-            hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, red, nred, s.sc, k, rel_error,
-                               (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fr,
-                               MailWait{nullptr, 0, 0, nullptr}, MailWait{c->mail->rr, 1, seq, c->direct_err}, c->bcast, plist_p(c), s.row0,
-                               (volatile int *)s.host_flags, no_post(), (const Mail *)c->mail, nb);
-            HIPCHK(c, hipGetLastError());
-            return 0;
-        }
-        // 2. x, r update + partial r.r
+        LAMCHK(hub_join(c, 0));
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
-            const double *red; int nred;
-            red_source(c, s, false, true, fin_a, &red, &nred);
-            const Finalize fb = make_finalize(c, s, true);
-            hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + (fb.active ? 1 : 0)), dim3(kBlock), 0, s.stream, red, nred,
-                               s.sc, k, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
-                               MailWait{nullptr, 0, 0, nullptr});
-            HIPCHK(c, hipGetLastError());
+            LAMCHK(phase_xr<I>(c, s, k, rel_error));
         }
-        LAMCHK(reduce_step(c, true, false, true, fin_b));
-        // 3. stop test + p update (into every replica)
-        PtrList pl = plist_p(c);
+        if (c->fuse_active) return 0;
+        LAMCHK(hub_join(c, 1));
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
-            const double *red; int nred;
-            red_source(c, s, true, false, fin_b, &red, &nred);
-            hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, red, nred, s.sc, k,
-                               rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows,
-                               (volatile int *)s.host_flags, MailWait{nullptr, 0, 0, nullptr}, no_post());
-            HIPCHK(c, hipGetLastError());
+            LAMCHK(phase_p<I>(c, s, k, rel_error));
         }
-        LAMCHK(gather_p_step(c));
+        if (c->rank_mode) return gather_p_rank(c);
+        LAMCHK(hub_join(c, 2));
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            LAMCHK(gather_wait(c, s));
+        }
         return 0;
     });
 }
+
+// ---- the host's view of the iteration's progress -----------------------------------------------------------------
+struct Progress { int iters, stop_at; };
+Progress read_progress(const ShardBase &s)
+{
+    const unsigned long long v = *reinterpret_cast<volatile unsigned long long *>(s.host_flags);
+    return {(int)(unsigned)(v & 0xffffffffull), (int)(unsigned)(v >> 32)};
+}
+
+// Wait until iteration `target` has made its stop decision (update_p_kernel's progress word in pinned memory), or
+// some iteration has stopped, or a bounded in-kernel wait has expired.  No event per iteration is involved: an event
+// record is a marker packet between the iteration's kernels.  A stream error (a fault, a lost device) ends the wait.
+int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
+{
+    unsigned spins = 0;
+    for (;;) {
+        const Progress pr = read_progress(s0);
+        if (pr.iters >= target || pr.stop_at != 0 || *(volatile int *)c->direct_err != 0) { *out = pr; return 0; }
+        if ((++spins & 4095u) == 0) {
+            const hipError_t e = hipStreamQuery(s0.stream);
+            if (e == hipSuccess) {
+                // everything enqueued has run: the word is final (it may have been written since the read above)
+                const Progress again = read_progress(s0);
+                if (again.iters >= target || again.stop_at != 0 || *(volatile int *)c->direct_err != 0) { *out = again; return 0; }
+                return fail(c, LAM_HIP_EHIP, "iteration %d was enqueued but never reported (progress word at %d)", target, again.iters);
+            }
+            if (e != hipErrorNotReady) return fail(c, LAM_HIP_EHIP, "stream error while iterating: %s", hipGetErrorString(e));
+            sched_yield();
+        } else {
+            __builtin_ia32_pause();
+        }
+    }
+}
+
+// Host barrier of the per-shard enqueue threads.  wait(flags) returns the OR of the flags every thread brought to
+// THIS barrier, so all threads leave the loop at the same barrier (a flag raised between two barriers is seen by
+// everybody at the next one, by nobody before).
+struct HostBarrier {
+    explicit HostBarrier(int n_) : n(n_) {}
+    const int n;
+    std::atomic<int> count{0}, gen{0}, acc{0};
+    int result[2] = {0, 0};
+    int wait(int flags)
+    {
+        if (flags) acc.fetch_or(flags, std::memory_order_acq_rel);
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            result[(g + 1) & 1] = acc.exchange(0, std::memory_order_acq_rel);
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+        } else {
+            unsigned spins = 0;
+            while (gen.load(std::memory_order_acquire) == g) {
+                if (++spins > 20000u) sched_yield(); else __builtin_ia32_pause();
+            }
+        }
+        return result[(g + 1) & 1];
+    }
+};
 
 }  // namespace
 
@@ -1192,7 +1464,7 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
         c->sh[q].dev = device_ids ? device_ids[q] : q % ndev;
     }
     int rc = create_common(c.get());
-    if (rc != 0) { for (auto &s : c->sh) { free_shard(s); release_handles(s); } return rc; }
+    if (rc != 0) { abandon(c.get()); return rc; }
     *out = c.release();
     return 0;
 }
@@ -1231,7 +1503,7 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     c->sh[0].index = rank;
     c->sh[0].dev = device_id;
     int rc = create_common(c.get());
-    if (rc != 0) { for (auto &s : c->sh) { free_shard(s); release_handles(s); } return rc; }
+    if (rc != 0) { abandon(c.get()); return rc; }
     if (c->rank_mode) {
         const double t0 = now_s();
         ncclUniqueId id;
@@ -1239,19 +1511,20 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
         // caller passed (the C++ class hands over an all-zero buffer when the launch has a single rank)
         if (unique_id && nranks > 1) memcpy(&id, unique_id, sizeof id);
         else if (ncclGetUniqueId(&id) != ncclSuccess) {
-            for (auto &s : c->sh) { free_shard(s); release_handles(s); }
+            abandon(c.get());
             return fail(nullptr, LAM_HIP_ERCCL, "ncclGetUniqueId failed");
         }
         (void)hipSetDevice(device_id);
-        // RCCL writes a five-line version banner to STDOUT when a communicator is created; the callers' stdout is
-        // a protocol (the drivers' CSV line, bench.py's JSON line), so it goes to stderr for the duration of the call
+        // RCCL writes a five-line version banner to STDOUT when a communicator is created.  Callers whose stdout
+        // is a protocol (this package's drivers: the CSV line) set LAM_HIP_QUIET_RCCL=1 and get it on stderr instead
+        // for the duration of the call; by default the library leaves the process's descriptors alone
         ncclResult_t r;
         {
             StdoutToStderr quiet;
             r = ncclCommInitRank(&c->comm, nranks, id, rank);
         }
         if (r != ncclSuccess) {
-            for (auto &s : c->sh) { free_shard(s); release_handles(s); }
+            abandon(c.get());
             return fail(nullptr, LAM_HIP_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));
         }
         c->t_comm_init = now_s() - t0;
@@ -1273,6 +1546,7 @@ void lam_hip_destroy(lam_hip_ctx *c)
     if (c->bcast) (void)hipFree(c->bcast);
     if (c->direct_err) (void)hipHostFree(c->direct_err);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    release_hub(c);
     for (auto &s : c->sh) {
         free_shard(s);
         release_handles(s);
@@ -1549,6 +1823,96 @@ int lam_hip_cg_init(lam_hip_ctx *c)
     return 0;
 }
 
+// GEMV device time of the iteration that used ring slot `slot` (shard 0), if that iteration was timed
+static void harvest_gemv_time(ShardBase &s0, int slot, double *ms_sum, int *samples)
+{
+    if (!s0.timed_slot[slot]) return;
+    s0.timed_slot[slot] = false;
+    float ms = 0.f, ms2 = 0.f;
+    if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (s0.split_slot[slot] && hipEventElapsedTime(&ms2, s0.ev_g2[slot], s0.ev_g3[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
+    *ms_sum += ms + ms2;
+    (*samples)++;
+}
+
+// The lag rule (every enqueue loop uses it).  Before enqueueing iteration k the host makes sure iteration k - kLag
+// has reported, then looks at the stopping iteration the update kernel left in pinned memory.  Later iterations may
+// or may not have finished by now -- that depends on how far this rank's GPU is ahead of its host -- so the value
+// only counts if it names an iteration whose report has been AWAITED: stop_at <= k - kLag.  A stop at iteration j
+// is therefore acted on at k = j + kLag on every rank, whatever the timing: all ranks enqueue the same number of
+// (no-op) iterations and their collectives stay matched.  (The reference broadcasts the decision instead:
+// MPI_Bcast(&stop), ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:404-407.)
+// Returns 0 go on, 1 stop here, 2 a bounded in-kernel wait expired (reported after the final sync), < 0 error.
+static int lag_check(lam_hip_ctx *c, ShardBase &s0, int k)
+{
+    Progress pr;
+    LAMCHK(await_progress(c, s0, k - kLag, &pr));
+    if (*(volatile int *)c->direct_err != 0) return 2;
+    // LAM_HIP_DEBUG_LEVEL_STOP: test hook that restores the timing-dependent decision ("any stop seen so far") so
+    // that the stream-ordered RCCL test double can be shown to catch the rank desynchronisation it causes
+    // (tests/test_gpu_rank_mock.py).  Never set it otherwise.
+    static const bool level_stop = getenv("LAM_HIP_DEBUG_LEVEL_STOP") != nullptr;
+    return (pr.stop_at != 0 && (pr.stop_at <= k - kLag || level_stop)) ? 1 : 0;
+}
+
+// One process, several shards: every shard is enqueued by a host thread of its own (the reference drives each device
+// from its own OpenMP thread, ConjugateGradient_MultiGPUS_CUDA.cu:264-283,337-378).  With one thread for P shards an
+// iteration costs the host 3P launches + ~3P event records + 3P(P-1) stream waits one after the other; here they are
+// issued P-wide, with a host barrier between the phases (a stream wait must follow the record it refers to).
+static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_error, int *enq_out, double *gemv_ms, int *gemv_samples)
+{
+    const int L = (int)c->sh.size();
+    HostBarrier bar(L);
+    std::vector<int> rcs(L, 0);
+    int enq = 0;
+    auto worker = [&](int q) {
+        ShardBase &s = c->sh[q];
+        int rc = set_dev(c, s);
+        auto phase = [&](auto &&fn) {               // run one phase unless this thread has already failed
+            if (rc == 0) rc = fn();
+            return bar.wait(rc != 0 ? 1 : 0);
+        };
+        for (int i = 0; i < iters; i++) {
+            const int k = k_first + i, slot = i % kLag;
+            if (i >= kLag) {
+                int flags = rc != 0 ? 1 : 0;
+                if (q == 0 && rc == 0) {
+                    const int d = lag_check(c, s, k);
+                    if (d < 0) { rc = d; flags |= 1; }
+                    else if (d != 0) flags |= 2;
+                    else harvest_gemv_time(s, slot, gemv_ms, gemv_samples);
+                }
+                if (bar.wait(flags) != 0) break;
+            }
+            const double te = q == 0 ? now_s() : 0.0;
+            // with the hub, thread 0 issues the join between two barriers (everybody's post before it, everybody's wait after it)
+            auto join = [&](int which) {
+                if (!hub_active(c)) return 0;
+                if (q == 0 && rc == 0) rc = hub_join(c, which);
+                return bar.wait(rc != 0 ? 1 : 0);
+            };
+            if (phase([&] { return dispatch(c, [&](auto impl) -> int { return phase_gemv<decltype(impl)>(c, s, k, slot); }); })) break;
+            if (join(0)) break;
+            if (phase([&] { return dispatch(c, [&](auto impl) -> int { return phase_xr<decltype(impl)>(c, s, k, rel_error); }); })) break;
+            if (join(1)) break;
+            if (phase([&] { return dispatch(c, [&](auto impl) -> int { return phase_p<decltype(impl)>(c, s, k, rel_error); }); })) break;
+            if (join(2)) break;
+            if (rc == 0) rc = gather_wait(c, s);       // refers to records issued before the last barrier: no barrier needed
+            if (q == 0) { enq++; c->enqueue_ns += (uint64_t)((now_s() - te) * 1e9); }
+        }
+        rcs[q] = rc;
+    };
+    std::vector<std::thread> th;
+    th.reserve(L);
+    for (int q = 1; q < L; q++) th.emplace_back(worker, q);
+    worker(0);
+    for (auto &t : th) t.join();
+    *enq_out = enq;
+    for (int q = 0; q < L; q++)
+        if (rcs[q] != 0) return rcs[q];
+    return 0;
+}
+
 int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stats *st)
 {
     if (!c) return LAM_HIP_EINVAL;
@@ -1559,57 +1923,49 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     double gemv_ms = 0.0;
     int gemv_samples = 0;
     int enq = 0;
-    bool stopped = false;
-    auto harvest = [&](int slot) {   // GEMV device time of a finished iteration
-        float ms = 0.f, ms2 = 0.f;
-        if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) != hipSuccess) return;
-        if (s0.split_slot[slot] && hipEventElapsedTime(&ms2, s0.ev_g2[slot], s0.ev_g3[slot]) != hipSuccess) return;
-        gemv_ms += ms + ms2;
-        gemv_samples++;
-    };
     // already converged in an earlier call?
     LAMCHK(set_dev(c, s0));
     HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
     HIPCHK(c, hipStreamSynchronize(s0.stream));
-    stopped = s0.sc_host->stop != 0;
+    const bool stopped = s0.sc_host->stop != 0;
     const int k_first = c->k_done + 1;
-    for (int i = 0; i < iters && !stopped; i++) {
-        const int k = k_first + i;
-        const int slot = i % kLag;
-        if (i >= kLag) {
-            // Iteration k - kLag (enqueued kLag steps ago) is done: harvest its GEMV time, then look at
-            // the stopping iteration update_p_kernel stores into pinned memory.  Later iterations may
-            // or may not have finished by now -- that depends on how far this rank's GPU is ahead of
-            // its host -- so the value only counts if it names an iteration whose completion has been
-            // AWAITED: flag <= k - kLag.  A stop at iteration j is therefore acted on at k = j + kLag
-            // on every rank, whatever the timing: all ranks enqueue the same number of (no-op)
-            // iterations and their collectives stay matched.  (The reference broadcasts the decision
-            // instead: MPI_Bcast(&stop), ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:404-407.)
-            LAMCHK(set_dev(c, s0));
-            HIPCHK(c, hipEventSynchronize(s0.ev_lag[slot]));
-            harvest(slot);
-            if (c->direct_err && *(volatile int *)c->direct_err != 0) break;    // reported after the sync below
-            const int stop_at = ((volatile int *)s0.host_flags)[1];
-            // LAM_HIP_DEBUG_LEVEL_STOP: test hook that restores the timing-dependent decision ("any stop
-            // seen so far") so that the stream-ordered RCCL test double can be shown to catch the rank
-            // desynchronisation it causes (tests/test_gpu_rank_mock.py).  Never set it otherwise.
-            static const bool level_stop = getenv("LAM_HIP_DEBUG_LEVEL_STOP") != nullptr;
-            if (stop_at != 0 && (stop_at <= k - kLag || level_stop)) { stopped = true; break; }
+    for (int i = 0; i < kLag; i++) s0.timed_slot[i] = false;
+    const bool threaded = !c->rank_mode && c->total_shards > 1 && c->opt_host_threads != 0 && !c->cg_direct && !c->cg_exchange1;
+    if (stopped) {
+        // nothing to enqueue
+    } else if (threaded) {
+        LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &gemv_ms, &gemv_samples));
+        c->gather_pending = false;
+    } else {
+        for (int i = 0; i < iters; i++) {
+            const int k = k_first + i;
+            const int slot = i % kLag;
+            if (i >= kLag) {
+                LAMCHK(set_dev(c, s0));
+                const int d = lag_check(c, s0, k);
+                if (d < 0) return d;
+                if (d != 0) break;
+                harvest_gemv_time(s0, slot, &gemv_ms, &gemv_samples);
+            }
+            const double te = now_s();
+            LAMCHK(enqueue_iteration(c, k, rel_error, slot));
+            c->enqueue_ns += (uint64_t)((now_s() - te) * 1e9);
+            enq++;
         }
-        LAMCHK(enqueue_iteration(c, k, rel_error, slot));
-        LAMCHK(set_dev(c, s0));
-        // update_p_kernel stores the stop flag straight into pinned host memory; mark the iteration
-        HIPCHK(c, hipEventRecord(s0.ev_lag[slot], s0.stream));
-        enq++;
     }
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
-    if (c->direct_err && *c->direct_err != 0)
-        return fail(c, LAM_HIP_EHIP, "direct exchange: rank %d: a bounded wait for a peer expired (code %d: 2 = partial dot product, 3 = p slice; "
-                                     "slot %d, expected tag %d:%d, saw %d:%d); the ranks are no longer in step", c->rank, c->direct_err[0],
+    if (*c->direct_err != 0) {
+        static const char *what[] = {"", "", "a peer's partial dot product (direct exchange)", "a peer's p slice (direct exchange)",
+                                     "the reducer workgroup's broadcast inside the fused update launch (its workgroups were not all resident?)",
+                                     "a workgroup's partial inside a launch (reducer workgroup)"};
+        const int code = c->direct_err[0];
+        return fail(c, LAM_HIP_EHIP, "rank %d: a bounded in-kernel wait expired waiting for %s (code %d; slot %d, expected tag %d:%d, saw %d:%d); "
+                                     "the iteration state is no longer valid", c->rank, code >= 2 && code <= 5 ? what[code] : "?", code,
                     c->direct_err[1], c->direct_err[4], c->direct_err[2], c->direct_err[5], c->direct_err[3]);
+    }
     // harvest the GEMV timings still in the ring
-    for (int j = std::max(0, enq - kLag); j < enq; j++) harvest(j % kLag);
+    for (int j = 0; j < kLag; j++) harvest_gemv_time(s0, j, &gemv_ms, &gemv_samples);
     LAMCHK(set_dev(c, s0));
     HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
     HIPCHK(c, hipStreamSynchronize(s0.stream));
@@ -1629,6 +1985,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         st->t_comm_init = c->t_comm_init;
         st->gemv_bytes = (double)c->esz_a() * (double)s0.nrows * (double)c->n + (double)c->esz_v() * (double)(c->n + s0.nrows);
     }
+    (void)enq;
     return 0;
 }
 
@@ -1985,8 +2342,12 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "finalize")) { c->opt_finalize = value; c->cg_ready = false; }
     else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
     else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
-    else if (!strcmp(name, "fuse_update")) c->opt_fuse = value;
-    else if (!strcmp(name, "symmetric")) c->opt_symmetric = value;
+    else if (!strcmp(name, "fuse_update")) { c->opt_fuse = value; c->cg_ready = false; }
+    else if (!strcmp(name, "symmetric")) { c->opt_symmetric = value; c->cg_ready = false; }   // other kernels, other partial arrays
+    else if (!strcmp(name, "gemv_timing")) c->opt_gemv_timing = value < 0 ? 0 : value;
+    else if (!strcmp(name, "host_threads")) c->opt_host_threads = value;
+    else if (!strcmp(name, "exchange_hub")) c->opt_hub = value;
+    else if (!strcmp(name, "assume_cus")) { c->opt_assume_cus = value; c->cg_ready = false; }
     else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
     else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;
     else return fail(c, LAM_HIP_EINVAL, "unknown option '%s'", name);
@@ -2010,6 +2371,16 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "reuse_matrix")) *value = c->opt_reuse_matrix;
     else if (!strcmp(name, "fuse_update")) *value = c->opt_fuse;
     else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
+    else if (!strcmp(name, "fuse_effective")) *value = c->fuse_active ? 1 : 0;
+    else if (!strcmp(name, "gemv_timing")) *value = c->opt_gemv_timing;
+    else if (!strcmp(name, "host_threads")) *value = c->opt_host_threads;
+    else if (!strcmp(name, "exchange_hub")) *value = c->opt_hub;
+    else if (!strcmp(name, "assume_cus")) *value = c->opt_assume_cus;
+    else if (!strcmp(name, "host_enqueue_ns")) *value = (int64_t)c->enqueue_ns;
+    else if (!strcmp(name, "hip_calls_launch")) *value = (int64_t)c->n_launch.load();
+    else if (!strcmp(name, "hip_calls_record")) *value = (int64_t)c->n_record.load();
+    else if (!strcmp(name, "hip_calls_wait")) *value = (int64_t)c->n_wait.load();
+    else if (!strcmp(name, "hip_calls_setdevice")) *value = (int64_t)c->n_setdev.load();
     else if (!strcmp(name, "symmetric")) *value = c->opt_symmetric;
     else if (!strcmp(name, "symmetric_effective")) *value = c->symv_active() ? 1 : 0;
     else if (!strcmp(name, "exchange_effective")) *value = c->cg_direct ? 2 : ((c->exchange1_ok() && !c->exchange2_wanted()) ? 1 : 0);

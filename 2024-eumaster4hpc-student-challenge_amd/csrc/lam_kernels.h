@@ -91,6 +91,18 @@ __device__ __forceinline__ double block_sum_array(const double *__restrict__ src
     return block_sum(v, s_red);
 }
 
+// The iteration's progress word in PINNED HOST memory, written by ONE thread per iteration with ONE 8-byte store:
+// low half = the iteration just finished, high half = that same iteration if it met the stop test (else 0).  The host
+// polls it instead of waiting on an event per iteration (no marker packets between the iteration's kernels); one
+// word, so it can never see a new iteration count next to an old stop decision.  After a stop the later (no-op)
+// iterations return before writing, so the stopping iteration stays readable.
+__device__ __forceinline__ void post_progress(volatile int *host_flags, int k, bool stop)
+{
+    if (host_flags == nullptr) return;
+    *reinterpret_cast<volatile unsigned long long *>(host_flags) =
+        ((unsigned long long)(unsigned)(stop ? k : 0) << 32) | (unsigned long long)(unsigned)k;
+}
+
 struct PtrList {                      // destinations of a replicated store (one per shard)
     void *p[kMaxShards];
     int n;
@@ -137,6 +149,8 @@ struct Finalize {
     PtrList dst;
     int slot;
     unsigned long long seq;           // mail: the iteration tag
+    int *host_err;                    // pinned host error word of the bounded waits (may be null): an expired wait is an
+                                      // error the caller sees (lam_hip_cg_iterate), never a silent NaN
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -225,7 +239,8 @@ __device__ __forceinline__ void publish_partial(double t, double *partial, const
 }
 
 // the reducer workgroup (every thread of it; workgroups wider than kBlock: the extra waves idle)
-__device__ __forceinline__ double reduce_partials_sum(double *partial, int n /*compute workgroups*/, double *s_red /*[kWaves]*/)
+__device__ __forceinline__ double reduce_partials_sum(double *partial, int n /*compute workgroups*/, double *s_red /*[kWaves]*/,
+                                                      int *host_err)
 {
     SpinGuard guard;
     bool timed_out = false;
@@ -246,7 +261,14 @@ __device__ __forceinline__ double reduce_partials_sum(double *partial, int n /*c
                 if (b[k] == kPartialSentinel) { b[k] = ld(base + k * kBlock); pending |= b[k] == kPartialSentinel; }
             if (pending) {
                 __builtin_amdgcn_s_sleep(8);
-                if (guard.slow_path() && guard.expired()) timed_out = true;
+                if (guard.slow_path()) {
+                    // another bounded wait of this solve has already expired: stop waiting (the solve has failed)
+                    if (host_err != nullptr && *(volatile int *)host_err != 0) timed_out = true;
+                    else if (guard.expired()) {
+                        timed_out = true;
+                        if (host_err != nullptr) { host_err[1] = base; host_err[2] = n; *(volatile int *)host_err = 5; }
+                    }
+                }
             }
         }
 #pragma unroll
@@ -287,7 +309,7 @@ __device__ __forceinline__ void post_total(const Finalize &f, double total)
 
 __device__ __forceinline__ void reduce_partials(double *partial, int n, const Finalize &f, double *s_red)
 {
-    post_total(f, reduce_partials_sum(partial, n, s_red));
+    post_total(f, reduce_partials_sum(partial, n, s_red, f.host_err));
 }
 
 // Hand-over INSIDE a launch (update_fused_kernel): the reducer workgroup publishes a scalar for the launch's
@@ -1178,7 +1200,7 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, double rel_error,
                 const TV *__restrict__ r, const TV *__restrict__ p_loc, PtrList pdst, uint64_t row0,
-                uint64_t n_loc, volatile int *host_flags /* pinned host: [0]=iters [1]=stopping iteration (0 = none) */,
+                uint64_t n_loc, volatile int *host_flags /* pinned host progress word, see post_progress */,
                 MailWait mw, MailPost post)
 {
     __shared__ double s_red[kWaves];
@@ -1192,10 +1214,8 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
         sc->rr[k & 1] = rr_new;
         sc->beta = beta_d;
         sc->iters = k;
-        if (host_flags != nullptr) {
-            host_flags[0] = k;
-            if (stop) host_flags[1] = k;      // WHICH iteration stopped: the host compares it with the
-        }                                     // iteration whose completion it has awaited (lam_hip_cg_iterate)
+        post_progress(host_flags, k, stop);   // WHICH iteration stopped: the host compares it with the iteration whose
+                                              // completion it has awaited (lam_hip_cg_iterate)
     }
     if (stop) {
         // every workgroup reaches the same decision from the same bits; a workgroup that starts
@@ -1280,7 +1300,7 @@ update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int
         // other workgroups through the two local broadcast slots
         const int nl = (int)gridDim.x - 1;                                             // listeners: compute workgroups (+ waiter)
         if (mw_pap.n > 0) bcast_post(bc, nl, mail_sum(mw_pap, s_red), seq);            // direct exchange: p.Ap of all ranks
-        const double local = reduce_partials_sum(partial, ncompute, s_red);           // this shard's r.r
+        const double local = reduce_partials_sum(partial, ncompute, s_red, host_err);  // this shard's r.r
         if (fin.mail) {
             post_total(fin, local);                                                    // ... to every rank's mailbox
             bcast_post(bc + kBcastLines, nl, mail_sum(mw_rr, s_red), seq);             // r.r of all ranks
@@ -1320,10 +1340,7 @@ update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int
         sc->rr[k & 1] = rr_new;
         sc->beta = beta_d;
         sc->iters = k;
-        if (host_flags != nullptr) {
-            host_flags[0] = k;
-            if (stop) host_flags[1] = k;
-        }
+        post_progress(host_flags, k, stop);
         if (stop) sc->stop = 1;
     }
     if (stop) return;
@@ -1434,10 +1451,8 @@ update_p_full_kernel(const double *__restrict__ red, int nred, CgScalars *sc, in
         sc->rr[k & 1] = rr_new;
         sc->beta = beta_d;
         sc->iters = k;
-        if (host_flags != nullptr) {
-            host_flags[0] = k;
-            if (stop) host_flags[1] = k;      // WHICH iteration stopped: the host compares it with the
-        }                                     // iteration whose completion it has awaited (lam_hip_cg_iterate)
+        post_progress(host_flags, k, stop);   // WHICH iteration stopped: the host compares it with the iteration whose
+                                              // completion it has awaited (lam_hip_cg_iterate)
     }
     if (stop) {
         if (blockIdx.x == 0 && threadIdx.x == 0) sc->stop = 1;

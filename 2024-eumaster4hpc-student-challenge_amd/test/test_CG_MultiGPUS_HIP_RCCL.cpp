@@ -61,6 +61,9 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L);
 
 int main(int argc, char **argv)
 {
+    // this program's stdout is a one-line CSV protocol: ask the library to keep RCCL's version banner (printed to
+    // stdout when the communicator is created) on stderr.  Opt-in: the library never moves a host's stdout by default.
+    setenv("LAM_HIP_QUIET_RCCL", "1", 0);
     lam_bootstrap::Launch L;
     if (!lam_bootstrap::init(&argc, &argv, L)) {
         fprintf(stderr, "bootstrap failed: %s\n", lam_hip_last_error(nullptr));

@@ -13,7 +13,11 @@ series is one problem.  The matrix is the device-generated random dense SPD syst
 (lam_hip_generate_random_spd, cond=1e6 so CG is still iterating at the end of the run).
 At N=1 GPU the line also carries, under "also", configs[1] (N=32768) and the sizes the reference
 published numbers for (N=10000/20000/40000, TESTS/BEST_RESULTS:362-372) with the per-iteration cost
-outside the GEMV ("other_us"); they run after the headline in the same process and context.
+outside the GEMV ("other_us"); they run after the headline in the same process and context.  Under
+"config4_gemv": BASELINE configs[3], the N=131072 fp32 / bf16-storage GEMV (VALU kernel and MFMA variant).
+For N > 1 GPUs the headline is the product's DEFAULT exchange (the other exchange modes are recorded under
+"exchange_modes" only), and every line checks itself: true == recursive residual, and for N > 1 the residual of
+the one-GPU solve of the same system; a failed check prints "value": null with the reason and exits non-zero.
 
 Under a launcher (RANK/WORLD_SIZE in the environment) every rank is one process on one GPU; the ranks
 find each other through the package's own socket rendezvous (no torch in the process: torch bundles a
@@ -183,6 +187,7 @@ def main():
                     help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes (roofline.traffic then "
                     "comes from profiles/traffic.json, tagged as such)")
+    ap.add_argument("--config4-n", type=int, default=131072, help="matrix order of the configs[3] GEMV-only side run")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
     args = ap.parse_args()
@@ -245,6 +250,9 @@ def main():
 
     n = args.n
     s = make_solver()
+    # HEADLINE = the product's default configuration of this topology (rank mode: lam_hip's default exchange), whatever
+    # the other exchange modes measure below; they are recorded under "exchange_modes" only.
+    default_exchange = s.get_option("exchange") if use_dist else None
     st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
     kernel_name = s.gemv_kernel_name()
 
@@ -256,13 +264,48 @@ def main():
 
     dt, st = max_over_ranks(dt, st)
     true_res = s.true_residual()
+
+    # Self-check of the headline (every GPU count): the recomputed true residual must equal the recursive one, and with
+    # more than one GPU the residual must agree with the SAME solve on one GPU (rank 0 runs it on its own device right
+    # here: N=65536 fits one MI355X).  A line that fails carries "value": null and the process exits non-zero.
+    check = {"true_vs_recursive": abs(true_res / st["rel_err"] - 1) if st["rel_err"] > 0 else float("inf"), "tolerance_true_vs_recursive": 1e-6}
+    failures = []
+    if not check["true_vs_recursive"] < 1e-6:
+        failures.append(f"true residual {true_res:.15e} != recursive residual {st['rel_err']:.15e}")
+    if n_gpus > 1 and not args.symmetric:
+        ref_err, ref_fail = None, None
+        if rank == 0:
+            try:
+                with lam.Solver(lam.F64, device_ids=[rdzv.local_rank % max(1, lam.device_count())] if rdzv else [0]) as ref:
+                    # LAM_BENCH_SELFTEST_FAIL=1 (tests only): the reference solves a DIFFERENT system, so the check must fail
+                    ref.generate_random_spd(n, 1234 + (1 if os.environ.get("LAM_BENCH_SELFTEST_FAIL") else 0), 1e6)
+                    ref.generate_random_rhs(1235)
+                    ref.cg_init()
+                    ref_err = ref.cg_iterate(args.warmup + args.steps, 0.0)["rel_err"]
+            except Exception as e:   # noqa: BLE001
+                ref_fail = f"one-GPU reference solve failed: {e}"[:300]
+        if rank == 0:
+            check["one_gpu_reference_residual"] = ref_err
+            check["tolerance_vs_one_gpu"] = 1e-9
+            if ref_err is None:
+                failures.append(ref_fail or "no one-GPU reference")
+            else:
+                check["vs_one_gpu"] = abs(st["rel_err"] / ref_err - 1)
+                if not check["vs_one_gpu"] < 1e-9:
+                    failures.append(f"residual after {args.warmup + args.steps} iterations {st['rel_err']:.15e} differs from the one-GPU solve {ref_err:.15e}")
+        if rdzv is not None:
+            rdzv.barrier()
+    check["passed"] = not failures
+    headline = {"dt": dt, "st": st, "true_res": true_res, "parallelism": parallelism}
+
     exchange_modes = None
     if rdzv is not None and (world > 1 or os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0")):
-        # Same problem, same context, the other exchange: ONE all-gather of [Ap slice | p.Ap partial] per
-        # iteration and redundant full-length r/p updates instead of all-gather x2 + all-gather(p).
-        # Both are product paths under the same parity tests; the headline is the faster one.
-        exchange_modes = {"allgather_x2+allgather_p": {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                                                       "gemv_ms": st["t_gemv"] * 1e3, "rel_residual_true": true_res}}
+        # Same problem, same context, the other exchanges of the rank mode (all product paths under the same parity
+        # tests) -- recorded for comparison, never the headline.
+        default_label = {0: "allgather_x2+allgather_p", 1: "allgather_Ap", 2: "direct_mailboxes"}.get(default_exchange, str(default_exchange))
+        exchange_modes = {"default": default_label,
+                          default_label: {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                                          "gemv_ms": st["t_gemv"] * 1e3, "rel_residual_true": true_res}}
 
         def timed(label, **opts):
             for k_, v_ in opts.items():
@@ -277,22 +320,25 @@ def main():
             dt_, st_ = max_over_ranks(time.perf_counter() - t0_, st_)
             res_ = s.true_residual()
             exchange_modes[label] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
-                                     "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_}
-            return dt_, st_, res_
+                                     "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
 
-        # A/B of the overlap (all-gather on the compute stream, GEMV unsplit), then the other exchange;
-        # the headline is the fastest of the three
-        base = f"row-sharded x{world}, 1 process/GPU, "
-        runs = [(dt, st, true_res, parallelism)]
-        runs.append(timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0) +
-                    (base + "RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration on one stream (no overlap)",))
-        runs.append(timed("allgather_Ap", exchange=1, overlap=1) +
-                    (base + "ONE RCCL all-gather of [Ap slice | p.Ap partial] per iteration (full-length r, p per rank)",))
+        if default_exchange == 0:
+            timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0)
+        else:
+            timed("allgather_x2+allgather_p", exchange=0, overlap=1)
+        if default_exchange != 1:
+            timed("allgather_Ap", exchange=1, overlap=1)
+        # Before the experimental part: should anything below take the process down, the headline is on record.
+        if rank == 0:
+            sys.stderr.write("[bench] provisional (before the direct-exchange runs): " + json.dumps(
+                {"value": args.steps / dt if not failures else None, "n_gpus": n_gpus, "ms_per_step": dt / args.steps * 1e3,
+                 "gemv_ms": st["t_gemv"] * 1e3, "self_check": check, "exchange_modes": exchange_modes}) + "\n")
+            sys.stderr.flush()
         # Last, because a failure here leaves the ranks' device state out of step: the direct exchange (peer-
-        # mapped mailboxes, no collective call inside the iteration).  Every step ends with an agreement over the
-        # control plane, so all ranks take the same path: a rank that cannot map its peers (all ranks then fall back
-        # to exchange 0) or a bounded wait that expires ends the attempt on ALL ranks, and nothing collective on the
-        # device follows it.
+        # mapped mailboxes, no collective call inside the iteration; EXPERIMENTAL until it has run on real peers).
+        # Every step ends with an agreement over the control plane, so all ranks take the same path: a rank that
+        # cannot map its peers (all ranks then fall back to exchange 0) or a bounded wait that expires ends the
+        # attempt on ALL ranks, and nothing collective on the device follows it.
         def agree(ok_):
             return all(x == b"1" for x in rdzv.allgather(b"1" if ok_ else b"0"))
 
@@ -309,7 +355,7 @@ def main():
             if s.get_option("exchange_effective") != 2:
                 raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
 
-        def try_direct(label, overlap, what):
+        def try_direct(label, overlap):
             """One timed run on the direct exchange; records it under `label`; True if it produced a number."""
             if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
                 exchange_modes[label] = {"error": "skipped (LAM_BENCH_DIRECT=0)"}
@@ -332,20 +378,18 @@ def main():
             dt_, st_ = max_over_ranks(dt_, st_)
             res_ = s.true_residual()
             exchange_modes[label] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
-                                     "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
-            # a candidate for the headline only if it solved the same problem: all exchanges are deterministic and
-            # agree to rounding, and the recomputed residual must match the recursive one
-            if abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / runs[0][2] - 1) < 1e-6:
-                runs.append((dt_, st_, res_, base + what))
-            else:
-                exchange_modes[label]["error"] = "residual differs from the RCCL exchanges: not used as the headline"
+                                     "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"], "experimental": True}
+            # it solved the same problem only if its residual matches the default exchange's (all exchanges are
+            # deterministic and agree to rounding) and the recomputed residual matches the recursive one
+            if not (abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / true_res - 1) < 1e-6):
+                exchange_modes[label]["error"] = "residual differs from the default exchange: WRONG RESULT on this hardware"
             return True
 
-        if try_direct("direct_mailboxes", 1, "direct stores into peer-mapped mailboxes and p replicas over xGMI (no collective call "
-                                             "inside the iteration); own-slice GEMV panel runs while the slices arrive"):
-            try_direct("direct_mailboxes, no split", 0, "direct stores into peer-mapped mailboxes and p replicas over xGMI (no collective "
-                                                        "call inside the iteration); one GEMV launch behind the flag wait")
-        dt, st, true_res, parallelism = min(runs, key=lambda r_: r_[0])
+        if default_exchange != 2 and try_direct("direct_mailboxes", 1):
+            try_direct("direct_mailboxes, no split", 0)
+        s.set_option("exchange", default_exchange)
+        s.set_option("overlap", 1)
+    dt, st, true_res, parallelism = headline["dt"], headline["st"], headline["true_res"], headline["parallelism"]
     n_coll = s.get_option("collectives_enqueued")
 
     # Side measurements, same process, same context, AFTER the headline (N=1 only, not under a profiler):
@@ -374,6 +418,30 @@ def main():
                 sys.stderr.write(f"[bench] side run N={n_also} failed: {e}\n")
     s.close()
 
+    # BASELINE configs[3]: N=131072 in fp32 and in bf16 storage (fp32 accumulate), GEMV only -- the production VALU
+    # kernel of each dtype and, for bf16, the MFMA-fed variant beside it (kept as an option: it is slower).  Own
+    # contexts, after the fp64 context has been closed; yardstick is still HBM GB/s (GEMV has no contraction for MFMA).
+    config4 = None
+    if solo and not args.no_also and not profiled and not args.symmetric:
+        config4 = []
+        n4 = args.config4_n
+        for dname, dt4, es4, variants in (("f32", lam.F32, 4, ((-1, "VALU (production)"),)),
+                                          ("bf16", lam.BF16, 2, ((-1, "VALU (production)"), (21, "MFMA v_mfma_f32_32x32x16_bf16, p as 3 bf16 terms"),
+                                                                 (20, "MFMA, p rounded to bf16")))):
+            try:
+                with lam.Solver(dt4) as s4:
+                    s4.generate_random_spd(n4, 1234, 1e4)
+                    s4.generate_random_rhs(1235)
+                    s4.cg_init()                              # p = b: a real vector in the GEMV's p replica
+                    for v4, what4 in variants:
+                        s4.set_option("gemv_variant", v4)
+                        ts = sorted(s4.gemv_only(10) for _ in range(3))
+                        gb = (es4 * float(n4) * n4 + 4.0 * 2 * n4) / 1e9
+                        config4.append({"n": n4, "dtype": dname, "path": what4, "kernel": s4.gemv_kernel_name(), "gemv_ms": ts[1] * 1e3,
+                                        "gemv_gbps": gb / ts[1], "roofline_frac": gb / ts[1] / HBM_PEAK_GBPS, "algorithmic_bytes": gb * 1e9})
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write(f"[bench] configs[3] run ({dname}) failed: {e}\n")
+
     ms_per_step = dt / args.steps * 1e3
     gemv_bytes = st["gemv_bytes"]                 # algorithmic bytes of ONE launch on one GPU
     achieved = gemv_bytes / st["t_gemv"] / 1e9 if st["t_gemv"] > 0 else 0.0
@@ -385,7 +453,7 @@ def main():
             traffic_src["live_measurement"] = live_traffic[1]
 
     out = {
-        "metric": "cg_iterations_per_sec", "value": args.steps / dt, "unit": "iterations/s",
+        "metric": "cg_iterations_per_sec", "value": (args.steps / dt) if not failures else None, "unit": "iterations/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
@@ -398,6 +466,7 @@ def main():
         "gemv_gbps_per_gpu": achieved,
         "gemv_gbps_aggregate": achieved * n_gpus,
         "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res, "rccl_init_s": st.get("t_comm_init", 0.0),
+        "self_check": check, **({"error": "; ".join(failures), "value_unchecked": args.steps / dt} if failures else {}),
         **({"exchange_modes": exchange_modes} if exchange_modes else {}),
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -412,8 +481,10 @@ def main():
 
     if also:
         out["also"] = also
+    if config4:
+        out["config4_gemv"] = config4
     if sym is not None:
-        sym["speedup_vs_headline"] = sym["value"] / out["value"]
+        sym["speedup_vs_headline"] = sym["value"] / (args.steps / dt)
         out["symmetric_option"] = sym
     if args.symmetric:
         out["config"]["workload"] += "; option symmetric=1 (upper-triangle product)"
@@ -430,6 +501,9 @@ def main():
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()
+    if failures:
+        sys.stderr.write("[bench] SELF-CHECK FAILED: " + "; ".join(failures) + "\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@ mirror the reference executables, run as real processes and compared with the re
 outputs (tests/golden) -- so these read like running the reference's drivers."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -144,6 +145,32 @@ def test_driver_csv_is_clean_with_real_rccl(tmp_path):
     assert len(lines) == 1, r.stdout
     f = lines[0].split(",")
     assert f[0] == "4096" and int(f[7]) == 16 and abs(float(f[8]) / 0.000368282 - 1) < 1e-5 and float(f[4]) > 0   # comm-init column
+
+
+def test_library_leaves_the_hosts_stdout_alone_by_default(tmp_path):
+    """Redirecting file descriptor 1 around ncclCommInitRank is OPT-IN (LAM_HIP_QUIET_RCCL=1, set by this package's
+    drivers): a host application that links liblam_hip.so keeps its stdout.  With the variable the banner RCCL
+    prints at communicator creation goes to stderr and stdout is exactly what the host wrote; without it the
+    library touches nothing (whatever RCCL prints lands between the host's own lines, in order)."""
+    code = ("import importlib, sys, os\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "lam = importlib.import_module('2024-eumaster4hpc-student-challenge_amd')\n"
+            "os.write(1, b'HOST-BEFORE\\n')\n"
+            "s = lam.Solver(lam.F64, rank=0, nranks=1, device_id=0, unique_id=None)\n"
+            "os.write(1, b'HOST-AFTER\\n')\n"
+            "s.generate_matrix(256); s.generate_rhs(); s.solve(5, 1e-9); s.close()\n")
+    outs = {}
+    for quiet in ("1", None):
+        env = dict(os.environ, LAM_HIP_FORCE_RCCL="1")
+        env.pop("LAM_HIP_QUIET_RCCL", None)
+        if quiet:
+            env["LAM_HIP_QUIET_RCCL"] = quiet
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[quiet] = r.stdout
+    assert outs["1"] == "HOST-BEFORE\nHOST-AFTER\n"
+    lines = outs[None].splitlines()
+    assert lines[0] == "HOST-BEFORE" and lines[-1] == "HOST-AFTER"       # nothing of the host's was diverted
 
 
 def test_mpi_bootstrapped_driver_single_rank(tmp_path):

@@ -582,3 +582,103 @@ def test_launch_chain_variants_are_bit_identical(lam, dtype_name, n, shards):
                 s.cg_iterate(7, 0.0)
             res[-1] += (s.solution().tobytes(),)
     assert res[0] == res[1] == res[2]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: residency guard of the fused launch, per-shard enqueue threads, event-free iteration loop
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype_name,n", [("F64", 4096), ("F32", 2048), ("F64", 1000)])
+def test_fused_update_needs_a_fully_resident_grid(lam, dtype_name, n):
+    """update_fused_kernel's workgroups wait for each other inside the launch, so it may only be used when the whole
+    grid is resident at once: cg_init asks the occupancy API x the CU count.  Pretending the device has ONE CU
+    (option assume_cus) must select the two-kernel form -- with the same bits."""
+    dt = getattr(lam, dtype_name)
+    res = []
+    for cus in (0, 1):
+        with lam.Solver(dt) as s:
+            s.generate_random_spd(n, 5, 300.0)
+            s.generate_random_rhs(6)
+            s.set_option("assume_cus", cus)
+            s.solve(400, 1e-9 if dtype_name == "F64" else 1e-5)
+            res.append((s.get_option("fuse_effective"), s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes()))
+    blocks = min(256, -(-n // 256)) + 2                # compute workgroups + reducer + waiter
+    assert res[0][0] == 1                              # a whole MI355X holds the grid ...
+    assert res[1][0] == (1 if blocks <= 8 else 0)      # ... one CU holds at most 8 workgroups of 256 threads
+    assert res[0][1:] == res[1][1:]
+
+
+@pytest.mark.parametrize("shards,n", [(2, 1024), (3, 3000), (8, 4096), (5, 1001)])
+def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
+    """One process, several shards, three ways of ordering the shards' streams from the host: the hub (default: the
+    streams meet at one join event per exchange), the all-to-all stream waits of round 2, and one enqueue thread per
+    shard (the reference's OpenMP-thread-per-device shape, MultiGPUS_CUDA.cu:337-378) -- same kernels, same stream
+    order per shard, same dependencies: identical bits, also when the solve stops early and when it is continued
+    in chunks."""
+    res = []
+    for threads, hub in ((0, 1), (0, 0), (1, 0), (1, 1)):
+        with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
+            s.generate_random_spd(n, 7, 200.0)
+            s.generate_random_rhs(8)
+            s.set_option("host_threads", threads)
+            s.set_option("exchange_hub", hub)
+            s.solve(500, 1e-9)
+            assert s.stats["converged"]
+            out = (s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes(), s.true_residual())
+            s.cg_init()
+            for chunk in (1, 2, 9, 30):
+                s.cg_iterate(chunk, 0.0)
+            res.append(out + (s.solution().tobytes(), s.stats["rel_err"]))
+    assert res[0] == res[1] == res[2] == res[3]
+
+
+def test_gemv_timing_can_be_sampled_or_off(lam):
+    """t_gemv comes from HIP-event pairs around the GEMV; each record is a marker packet between the iteration's
+    kernels, so they can be taken every T-th iteration or not at all (the host follows the iteration through a
+    progress word in pinned memory, not through events).  Same bits in every setting."""
+    res = []
+    with lam.Solver(lam.F64) as s:
+        s.generate_random_spd(4096, 9, 1e4)
+        s.generate_random_rhs(10)
+        for timing in (1, 4, 0):
+            s.set_option("gemv_timing", timing)
+            s.cg_init()
+            st = s.cg_iterate(50, 0.0)
+            assert (st["t_gemv"] > 0) == (timing != 0)
+            assert st["num_iters"] == 51
+            res.append((st["rel_err"], s.solution().tobytes()))
+    assert res[0] == res[1] == res[2]
+
+
+def test_stop_is_seen_without_events(lam, oracle):
+    """The stopping iteration reaches the host through the progress word: a solve that converges after a few
+    iterations returns the converging iteration however far ahead the host had enqueued, and later calls are no-ops."""
+    n = 512
+    rng = np.random.default_rng(3)
+    A = rng.uniform(-1, 1, (n, n)); A = A @ A.T / n + 4.0 * np.eye(n)
+    b = rng.uniform(-1, 1, n)
+    with lam.Solver(lam.F64) as s:
+        s.set_matrix(A); s.set_rhs(b)
+        s.solve(10000, 1e-10)
+        it = s.stats["num_iters"]
+        assert s.stats["converged"] and 3 < it < 200
+        x = s.solution()
+        st = s.cg_iterate(50, 1e-10)                  # already converged: nothing runs
+        assert st["num_iters"] == it and np.array_equal(x, s.solution())
+    _, st_ref = oracle.cg_solve(A, b, 10000, 1e-10)
+    assert abs(it - st_ref["num_iters"]) <= 3
+
+
+def test_changing_the_product_kernel_needs_a_new_cg_init(lam):
+    """Options that change which kernels / partial arrays an iteration uses invalidate the CG state (ADVICE r2:
+    'symmetric' used to leave cg_ready set and the reducer then read stale partials)."""
+    with lam.Solver(lam.F64) as s:
+        s.generate_random_spd(4096, 5, 100.0)
+        s.generate_random_rhs(6)
+        s.cg_init()
+        s.cg_iterate(3, 0.0)
+        for opt, val in (("symmetric", 1), ("symmetric", 0), ("fuse_update", 0), ("finalize", 0)):
+            s.set_option(opt, val)
+            with pytest.raises(lam.LamHipError):
+                s.cg_iterate(1, 0.0)
+            s.cg_init()
+            s.cg_iterate(3, 0.0)

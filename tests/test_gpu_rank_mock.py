@@ -229,12 +229,20 @@ def _check_bench_line(r, nproc):
     out = json.loads(lines[0])
     assert out["n_gpus"] == nproc and out["steps"] == 20 and out["scaling"] == "strong" and out["dtype"] == "f64"
     assert out["metric"] == "cg_iterations_per_sec" and out["value"] > 0
-    assert set(out["exchange_modes"]) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap",
-                                          "direct_mailboxes", "direct_mailboxes, no split"}
-    for m in out["exchange_modes"].values():
-        assert m.get("value", 0) > 0, out["exchange_modes"]
+    modes = {k: v for k, v in out["exchange_modes"].items() if k != "default"}
+    assert set(modes) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap",
+                          "direct_mailboxes", "direct_mailboxes, no split"}
+    for m in modes.values():
+        assert m.get("value", 0) > 0 and "error" not in m, out["exchange_modes"]
+    # the headline is the product's DEFAULT exchange, whatever the others measured (never a minimum over variants)
+    assert out["exchange_modes"]["default"] == "allgather_x2+allgather_p"
+    assert out["value"] == modes["allgather_x2+allgather_p"]["value"]
+    assert "RCCL all-gather x2" in out["config"]["parallelism"]
+    # ... and it checked itself: true == recursive residual, and the same residual as the one-GPU solve of the system
+    sc = out["self_check"]
+    assert sc["passed"] and sc["true_vs_recursive"] < 1e-6 and sc["vs_one_gpu"] < 1e-9, sc
     # both exchanges solved the same problem: true residuals agree (different rounding only)
-    res = [m["rel_residual_true"] for m in out["exchange_modes"].values()]
+    res = [m["rel_residual_true"] for m in modes.values()]
     assert all(abs(r_ / res[0] - 1) < 1e-6 for r_ in res)
     assert abs(out["rel_residual_true"] / out["rel_residual_recursive"] - 1) < 1e-6
     rf = out["roofline"]
@@ -267,7 +275,7 @@ def test_bench_torchrun_path_on_async_mock_across_processes(mock_async, tmp_path
 
 @pytest.mark.parametrize("hook,expect", [
     ({"LAM_HIP_DIRECT_DISABLE": "1"}, "fell back"),               # a rank cannot map its peers: all fall back together
-    ({"LAM_HIP_DEBUG_DIRECT_DROP": "1"}, "bounded wait"),          # a rank stops posting: every wait downstream expires
+    ({"LAM_HIP_DEBUG_DIRECT_DROP": "1"}, "bounded in-kernel wait"),  # a rank stops posting: every wait downstream expires
 ])
 def test_bench_survives_a_failing_direct_exchange(mock_mp_lib, tmp_path, hook, expect):
     """The direct exchange is tried last in bench.py; when it cannot be set up, or a peer goes silent in the
@@ -283,6 +291,18 @@ def test_bench_survives_a_failing_direct_exchange(mock_mp_lib, tmp_path, hook, e
     for k in ("allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap"):
         assert out["exchange_modes"][k]["value"] > 0
     assert out["value"] > 0 and "direct" not in out["config"]["parallelism"]
+
+
+def test_bench_line_fails_loudly_when_the_self_check_fails(mock_mp_lib, tmp_path):
+    """A multi-GPU line whose residual does not match the one-GPU solve of the same system must not look like a
+    result: "value" is null, the reason is in the line, the exit code is non-zero (hook: the reference solves another system)."""
+    r = _bench_torchrun(mock_mp_lib, 2, tmp_path, extra_env={"LAM_BENCH_SELFTEST_FAIL": "1", "LAM_BENCH_DIRECT": "0"})
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["self_check"]["passed"] is False and "differs from the one-GPU solve" in out["error"]
+    assert out["value_unchecked"] > 0
 
 
 def test_bench_stdout_is_one_json_line_with_real_rccl(tmp_path):
