@@ -409,3 +409,51 @@ def test_generator_tool_with_the_reference_cli(tmp_path, oracle):
     x = oracle.read_bin(sol).reshape(-1)
     x_ref, st = oracle.cg_solve(A, b, 2000, 1e-10)
     assert st["converged"] and np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own parameter grids and published known answers
+# ------------------------------------------------------------------------------------------------
+SWEEP = os.path.join(ROOT, "tools", "sweep.py")
+
+
+def test_reference_generate_grid_known_answers(tmp_path):
+    """`-s N -i 15` for N = 80000 ... 180000 through the drop-in driver, one process per point like the reference's
+    SLURM scripts (TESTS/CPU_SCRIPTS/CPU_8_NODE_gen.sh:24-32), against the `iters, err` columns the reference itself
+    printed for the same parameters (tests/golden/reference_gen_grid.json <- TESTS/BEST_RESULTS:173-215): 16 and
+    8.33333e-05 ... 5.55555e-05, to the printed digits.  N = 200000 needs 320 GB in fp64 -- more than one MI355X has --
+    so that point runs in fp32 storage and is marked; it is not shrunk."""
+    js = tmp_path / "gen.json"
+    r = subprocess.run([sys.executable, SWEEP, "--grid", "gen", "--json", str(js), "--csv", str(tmp_path / "gen.csv")],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    import json
+    recs = json.load(open(js))
+    gold = json.load(open(os.path.join(GOLDEN, "reference_gen_grid.json")))["entries"]
+    assert [x["n"] for x in recs] == [e["n"] for e in gold] == [80000, 90000, 100000, 110000, 120000, 140000, 160000, 180000, 200000]
+    for x, e in zip(recs, gold):
+        assert x["match"] and x["iters"] == 16 == e["iters_printed"], x
+        assert x["precision"] == ("f64" if x["n"] <= 180000 else "f32")
+        assert x["rel_diff"] <= (2e-6 if x["precision"] == "f64" else 1e-5), x
+        assert len(x["csv"].split(",")) == 10 and x["csv"].split(",")[0] == str(x["n"])
+    assert "does not" not in recs[0].get("note", "") and "f32" in recs[-1]["note"]
+    # most points agree with the reference's printed digits character for character
+    assert sum(x["same_printed_digits"] for x in recs[:-1]) >= 6
+
+
+def test_reference_file_grid_sizes(tmp_path):
+    """The file-mode sizes of TESTS/GPU_SCRIPTS/GPU_1_NODE.sh:41-47 (10000 ... 70000, default tolerance 1e-9): the
+    reference's matrix files were never published, so the systems are generated on the device; the smallest one also
+    goes through real files written by the generator tool (reference CLI) and the -A/-b loaders.  Every point prints
+    the reference's 10 CSV columns and converges below the tolerance."""
+    js = tmp_path / "file.json"
+    r = subprocess.run([sys.executable, SWEEP, "--grid", "file", "--json", str(js), "--files", str(tmp_path), "--files-max-n", "10000"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    import json
+    recs = json.load(open(js))
+    assert [x["n"] for x in recs] == [10000, 20000, 30000, 40000, 50000, 60000, 70000]
+    assert "file mode" in recs[0]["mode"] and all("device-generated" in x["mode"] for x in recs[1:])
+    for x in recs:
+        f = x["csv"].split(",")
+        assert x["match"] and len(f) == 10 and f[0] == str(x["n"]) and f[1] == "1" and float(f[8]) < 1e-9 and float(f[5]) > 0
