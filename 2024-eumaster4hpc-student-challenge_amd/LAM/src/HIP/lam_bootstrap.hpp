@@ -17,6 +17,7 @@
 #include <string>
 #include <thread>
 
+#include <fcntl.h>
 #include <unistd.h>
 
 #include "../../../../include/lam_hip.h"
@@ -101,10 +102,13 @@ inline bool attach(Launch &L)
     if (L.rank == 0) {
         if (lam_hip_get_unique_id(L.unique_id) != 0) return false;
         unlink(path.c_str());              // whatever an earlier launch left under this name is not ours
-        const std::string tmp = path + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(L.unique_id, 1, LAM_HIP_UNIQUE_ID_BYTES, f) != LAM_HIP_UNIQUE_ID_BYTES) return false;
-        fclose(f);
+        // created exclusively and never through a symlink planted at the predictable name, readable by this user only
+        const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+        unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        if (fd < 0) return false;
+        const bool written = write(fd, L.unique_id, LAM_HIP_UNIQUE_ID_BYTES) == (ssize_t)LAM_HIP_UNIQUE_ID_BYTES;
+        if (close(fd) != 0 || !written) { unlink(tmp.c_str()); return false; }
         return rename(tmp.c_str(), path.c_str()) == 0;
     }
     for (int tries = 0; tries < 6000; tries++) {   // up to 60 s

@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liblam_hip.so")
+# LAM_HIP_LIB: load another build of the same ABI instead (the tuning build liblam_hip_tuning.so, tools/gemv_probe.py)
+_LIB = os.environ.get("LAM_HIP_LIB") or os.path.join(_HERE, "liblam_hip.so")
+TUNING_LIB = os.path.join(_HERE, "liblam_hip_tuning.so")
 
 F64, F32, BF16 = 0, 1, 2
 _VEC_DTYPE = {F64: np.float64, F32: np.float32, BF16: np.float32}

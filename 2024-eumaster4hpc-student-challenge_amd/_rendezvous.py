@@ -51,6 +51,8 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > (1 << 30):
+        raise ValueError("rendezvous: implausible message length")
     return _recv_exact(sock, n)
 
 
@@ -76,7 +78,13 @@ class Rendezvous:
             srv.listen(self.size)
             nonce = os.urandom(8).hex()
             tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "w") as f:
+            # created exclusively, never through a symlink somebody planted at the predictable name, readable by us only
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as f:
                 f.write(f"{srv.getsockname()[1]} {nonce}\n")
             os.replace(tmp, path)             # atomic: readers see the old file or the new one, never half
             self._file = path
@@ -94,13 +102,20 @@ class Rendezvous:
                     conn, _ = srv.accept()
                 except socket.timeout:
                     continue
-                conn.settimeout(timeout)
+                # the hello gets a short timeout of its own: a stray local connection that says nothing must not hold
+                # the accept loop (and its deadline check) for the whole rendezvous timeout
+                conn.settimeout(2.0)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                hello = _recv(conn).decode().split()
-                if len(hello) != 2 or hello[1] != nonce or not (0 < int(hello[0]) < self.size) or int(hello[0]) in peers:
-                    conn.close()              # somebody holding a stale file: not one of ours
+                try:
+                    hello = _recv(conn).decode("ascii", "replace").split()
+                    peer = int(hello[0]) if len(hello) == 2 and hello[1] == nonce else -1
+                except (OSError, ValueError, ConnectionError, struct.error):
+                    peer = -1                 # garbage, a timeout, or a peer that hung up: not one of ours
+                if not (0 < peer < self.size) or peer in peers:
+                    conn.close()              # somebody holding a stale file, or not a rank at all
                     continue
-                peers[int(hello[0])] = conn
+                conn.settimeout(timeout)
+                peers[peer] = conn
                 _send(conn, b"ok")
             srv.close()
             self._peers = [peers[r] for r in range(1, self.size)]

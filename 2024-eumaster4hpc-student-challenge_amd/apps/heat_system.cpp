@@ -24,6 +24,17 @@ namespace
 {
 const double BC_NORTH = 0.0, BC_SOUTH = 100.0, BC_WEST = 100.0, BC_EAST = 100.0;
 
+// closes on every exit path (the early `return 2`s used to leak the handles)
+struct File {
+    FILE *f;
+    File(const char *path, const char *mode) : f(fopen(path, mode)) {}
+    ~File() { if (f) fclose(f); }
+    File(const File &) = delete;
+    File &operator=(const File &) = delete;
+    operator FILE *() const { return f; }
+    bool close() { const bool ok = f == nullptr || fclose(f) == 0; f = nullptr; return ok; }
+};
+
 bool write_header(FILE *f, uint64_t rows, uint64_t cols)
 {
     const uint64_t h[2] = {rows, cols};
@@ -34,9 +45,8 @@ int assemble(size_t nx, size_t ny, const char *mpath, const char *bpath)
 {
     if (nx < 3 || ny < 3) { fprintf(stderr, "need nx, ny >= 3\n"); return 1; }
     const size_t mx = nx - 2, my = ny - 2, n = mx * my;
-    FILE *fm = fopen(mpath, "wb");
-    FILE *fb = fopen(bpath, "wb");
-    if (!fm || !fb) { fprintf(stderr, "Cannot open output file\n"); return 2; }
+    File fm(mpath, "wb"), fb(bpath, "wb");
+    if (!fm.f || !fb.f) { fprintf(stderr, "Cannot open output file\n"); return 2; }
     if (!write_header(fm, n, n) || !write_header(fb, n, 1)) return 2;
     std::vector<double> row(n), rhs(n, 0.0);
     for (size_t y = 1; y <= my; y++)
@@ -51,8 +61,7 @@ int assemble(size_t nx, size_t ny, const char *mpath, const char *bpath)
             if (fwrite(row.data(), sizeof(double), n, fm) != n) return 2;
         }
     if (fwrite(rhs.data(), sizeof(double), n, fb) != n) return 2;
-    fclose(fm);
-    fclose(fb);
+    if (!fm.close() || !fb.close()) { fprintf(stderr, "Cannot write output file\n"); return 2; }
     printf("heat system: grid %zux%zu -> n=%zu unknowns, dense matrix %.3f GB\n", nx, ny, n, n * (double)n * 8 / 1e9);
     return 0;
 }
@@ -60,15 +69,15 @@ int assemble(size_t nx, size_t ny, const char *mpath, const char *bpath)
 int field(size_t nx, size_t ny, const char *spath, const char *hpath)
 {
     const size_t mx = nx - 2, my = ny - 2, n = mx * my;
-    FILE *fs = fopen(spath, "rb");
-    if (!fs) { fprintf(stderr, "Cannot open solution file\n"); return 2; }
+    File fs(spath, "rb");
+    if (!fs.f) { fprintf(stderr, "Cannot open solution file\n"); return 2; }
     uint64_t h[2];
     std::vector<double> x(n);
     if (fread(h, sizeof(uint64_t), 2, fs) != 2 || h[0] != n || fread(x.data(), sizeof(double), n, fs) != n) {
         fprintf(stderr, "solution file does not hold %zu values\n", n);
         return 2;
     }
-    fclose(fs);
+    fs.close();
     std::vector<double> heat(nx * ny, 0.0);
     for (size_t i = 1; i + 1 < nx; i++) { heat[(ny - 1) * nx + i] = BC_NORTH; heat[i] = BC_SOUTH; }
     for (size_t j = 1; j + 1 < ny; j++) { heat[j * nx] = BC_WEST; heat[j * nx + nx - 1] = BC_EAST; }
@@ -78,12 +87,11 @@ int field(size_t nx, size_t ny, const char *spath, const char *hpath)
     heat[(ny - 1) * nx + nx - 1] = (BC_NORTH + BC_EAST) / 2;
     for (size_t y = 1; y <= my; y++)
         for (size_t xx = 1; xx <= mx; xx++) heat[y * nx + xx] = x[(y - 1) * mx + (xx - 1)];
-    FILE *fh = fopen(hpath, "wb");
-    if (!fh || !write_header(fh, ny, nx) || fwrite(heat.data(), sizeof(double), nx * ny, fh) != nx * ny) {
+    File fh(hpath, "wb");
+    if (!fh.f || !write_header(fh, ny, nx) || fwrite(heat.data(), sizeof(double), nx * ny, fh) != nx * ny || !fh.close()) {
         fprintf(stderr, "Cannot write heat file\n");
         return 2;
     }
-    fclose(fh);
     return 0;
 }
 }  // namespace

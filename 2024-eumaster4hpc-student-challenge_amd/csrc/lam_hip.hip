@@ -151,6 +151,9 @@ struct lam_hip_ctx {
     uint64_t problem_gen = 0, direct_gen = ~0ull;   // direct mappings belong to one set_problem generation
     bool direct_ok = false;
     bool cg_direct = false;                     // the current CG state runs on the direct exchange
+    int64_t opt_verify_direct = 1;              // lam_hip_solve on the direct exchange: compare the recomputed residual with
+                                                // the recursive one afterwards; on a mismatch solve again on the RCCL exchange
+    int64_t direct_fallbacks = 0;               // how often that happened
     uint32_t epoch = 0;                         // bumped by every cg_init: mailbox tags never repeat
     int *direct_err = nullptr;                  // pinned host: a bounded in-kernel wait expired ([0] = which, see cg_iterate)
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
@@ -299,11 +302,21 @@ struct Impl {
     static constexpr int VEC = MatVec<TA>::N;
 
     // GEMV shapes.  Variants 0-8: gemv_tile_kernel {rows per wave, p-tile columns, p in LDS, rotated
-    // tile order}; 9-18: gemv_coop_kernel {rows per workgroup, tile, waves}.  Variant 10 (cooperative
-    // rows, 2 rows per 4-wave workgroup) is the production shape -- measured fastest at N=65536 and
-    // N=32768 (profiles/r01_gemv_variant_sweep.txt); the others stay selectable with
-    // lam_hip_set_option("gemv_variant") for tuning runs (tools/gemv_probe.py).
+    // tile order}; 9-18: gemv_coop_kernel {rows per workgroup, tile, waves}; 19-22: the MFMA experiment (bf16).
+    // The PRODUCT library holds the shapes that are some dtype's default or part of a reported comparison:
+    // 10 (cooperative rows, 2 rows per 4-wave workgroup: fp64/fp32 production, fastest at N=65536 and N=32768,
+    // profiles/r01_gemv_variant_sweep.txt), 0 (4 rows per wave: bf16 production), 21 / 20 (MFMA-fed bf16, p exact /
+    // p rounded: BASELINE configs[3]'s comparison).  The other 19 are tuning scaffolding and exist only in the
+    // library built with -DLAM_TUNING_VARIANTS (`make tuning` -> liblam_hip_tuning.so, used by tools/gemv_probe.py).
     static constexpr int kNumVariants = 23;
+    static bool variant_available(int v)
+    {
+#ifdef LAM_TUNING_VARIANTS
+        return v >= 0 && v < kNumVariants;
+#else
+        return v == 0 || v == 10 || v == 20 || v == 21;
+#endif
+    }
     // rows per WORKGROUP of each variant (variants 9.. are the cooperative-row shape: R rows per workgroup)
     static int variant_rows_per_block(int v)
     {
@@ -315,7 +328,7 @@ struct Impl {
     static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic && (c->n % VEC) == 0; }
     static int variant(const lam_hip_ctx *c)
     {
-        if (c->opt_gemv_variant >= 0 && c->opt_gemv_variant < kNumVariants) return (int)c->opt_gemv_variant;
+        if (c->opt_gemv_variant >= 0 && variant_available((int)c->opt_gemv_variant)) return (int)c->opt_gemv_variant;
         // production shapes: fp64/fp32 -> cooperative rows (variant 10); bf16 storage spends more VALU
         // per byte (widening) and measures best with 4 rows per wave (variant 0, 6.77 vs 6.40 TB/s)
         return sizeof(TA) == 2 ? 0 : 10;
@@ -344,8 +357,10 @@ struct Impl {
         else if (v <= 18)
             snprintf(buf, sizeof buf, "gemv_coop_kernel<%s,%s,R=%d,TILE=%d,NT=%s,UNROLL=%d,WAVES=%d>", ta, tv, coops[v - 9].r,
                      coops[v - 9].tile, nt, coops[v - 9].unroll, coops[v - 9].waves);
-        else
-            snprintf(buf, sizeof buf, "gemv_mfma_bf16_kernel<variant %d>", v);
+        else {
+            static const int mf[4][2] = {{2, 3}, {2, 1}, {4, 3}, {1, 3}};      // {R, SPLIT} of variants 19..22
+            snprintf(buf, sizeof buf, "gemv_mfma_bf16_kernel<R=%d,TILE=4096,NT=true,SPLIT=%d>", mf[v - 19][0], mf[v - 19][1]);
+        }
         return buf;
     }
 
@@ -442,6 +457,8 @@ struct Impl {
             switch (variant(c)) {
             default:
             case 0: launch_tile<4, 4096, true, true>(c, grid, s.stream, a); break;
+            case 10: launch_coop<2>(c, grid, s.stream, a); break;
+#ifdef LAM_TUNING_VARIANTS
             case 1: launch_tile<2, 4096, true, true>(c, grid, s.stream, a); break;
             case 2: launch_tile<8, 4096, true, true>(c, grid, s.stream, a); break;
             case 3: launch_tile<4, 2048, true, true>(c, grid, s.stream, a); break;
@@ -451,7 +468,6 @@ struct Impl {
             case 7: launch_tile<4, 4096, true, false>(c, grid, s.stream, a); break;
             case 8: launch_tile<1, 4096, true, true>(c, grid, s.stream, a); break;
             case 9: launch_coop<1>(c, grid, s.stream, a); break;
-            case 10: launch_coop<2>(c, grid, s.stream, a); break;
             case 11: launch_coop<4>(c, grid, s.stream, a); break;
             case 12: launch_coop<8>(c, grid, s.stream, a); break;
             case 13: launch_coop<2, 4096, 8>(c, grid, s.stream, a); break;
@@ -460,13 +476,17 @@ struct Impl {
             case 16: launch_coop<2, 8192, 4, 8>(c, grid, s.stream, a); break;
             case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
             case 18: launch_coop<3>(c, grid, s.stream, a); break;
+#endif
             case 19: case 20: case 21: case 22:
                 if constexpr (sizeof(TA) == 2) {
                     const int v = variant(c);
-                    if (v == 19) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
-                    else if (v == 20) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 1>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+                    if (v == 20) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 1>), dim3(grid), dim3(kBlock), 0, s.stream, a);
                     else if (v == 21) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<4, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
-                    else hipLaunchKernelGGL((gemv_mfma_bf16_kernel<1, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+#ifdef LAM_TUNING_VARIANTS
+                    else if (v == 19) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+                    else if (v == 22) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<1, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
+#endif
+                    else return fail(c, LAM_HIP_EINVAL, "gemv_variant %d is not in this build", v);
                 } else {
                     return fail(c, LAM_HIP_EINVAL, "gemv_variant 19-22 (MFMA) exist for LAM_HIP_BF16 only");
                 }
@@ -1055,6 +1075,14 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
             uint64_t r0 = 0, nr = 0;
             if (q < P) partition(c->n, P, q, &r0, &nr);
             nb.n[q] = q < P ? vec_grid(nr) : 0;
+        }
+        // LAM_HIP_DEBUG_DIRECT_STALE=<rank>: test hook -- that rank's p replica is perturbed in front of the GEMV of
+        // iteration 3, which is what a stale read of a peer's slice would amount to: the ranks stay in step, the result
+        // is wrong, and lam_hip_solve's residual check must notice and solve again on the RCCL exchange.  Never set it otherwise.
+        static const char *stale = getenv("LAM_HIP_DEBUG_DIRECT_STALE");
+        if (stale && *stale && atoi(stale) == c->rank && k == 3) {
+            hipLaunchKernelGGL((axpby_kernel<TV>), dim3(vec_grid(c->n)), dim3(kBlock), 0, s.stream, (TV)0, (const TV *)s.p, (TV)1.001, (TV *)s.p, c->n);
+            LAUNCHED(c);
         }
         // the fused update launch of iteration k-1 may have waited for the slices already (its waiter workgroup)
         const bool need_wait = P > 1 && k > 1 && c->waited_k != k - 1;
@@ -1994,9 +2022,31 @@ int lam_hip_solve(lam_hip_ctx *c, int max_iters, double rel_error, lam_hip_stats
     if (!c) return LAM_HIP_EINVAL;
     if (max_iters < 0) return fail(c, LAM_HIP_EINVAL, "max_iters must be >= 0");
     const double t0 = now_s();
+    lam_hip_stats local;
     LAMCHK(lam_hip_cg_init(c));
-    LAMCHK(lam_hip_cg_iterate(c, max_iters, rel_error, st));
-    if (st) st->t_total = now_s() - t0;
+    LAMCHK(lam_hip_cg_iterate(c, max_iters, rel_error, &local));
+    if (c->cg_direct && c->opt_verify_direct) {
+        // The direct exchange (EXPERIMENTAL until it has run on real peers, see lam_hip.h) hands p slices over
+        // through peer-mapped memory and flags; if a rank ever read a slice that was not there yet, the recursion
+        // would drift away from b - A x.  So the solve checks itself: the recomputed residual (a collective: every
+        // rank gets the same number and takes the same branch) against the recursive one, with room for the
+        // attainable accuracy of the dtype.  On a mismatch the system is solved again on the RCCL exchange.
+        double tr = 0.0;
+        LAMCHK(lam_hip_true_residual(c, &tr));
+        const double slack = 100.0 * std::sqrt(c->dtype == LAM_HIP_F64 ? 2.220446049250313e-16 : 5.9604644775390625e-08);
+        if (!(tr <= 10.0 * local.rel_err + slack)) {
+            if (c->rank == 0)
+                fprintf(stderr, "lam_hip: direct exchange: recomputed residual %.3e does not match the recursive residual %.3e -- "
+                                "solving again on the RCCL exchange\n", tr, local.rel_err);
+            c->direct_fallbacks++;
+            c->opt_exchange = 0;
+            c->cg_ready = false;
+            LAMCHK(lam_hip_cg_init(c));
+            LAMCHK(lam_hip_cg_iterate(c, max_iters, rel_error, &local));
+        }
+    }
+    local.t_total = now_s() - t0;
+    if (st) *st = local;
     return 0;
 }
 
@@ -2333,7 +2383,12 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *c, char *buf, size_t len)
 int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return LAM_HIP_EINVAL;
-    if (!strcmp(name, "gemv_variant")) c->opt_gemv_variant = value;
+    if (!strcmp(name, "gemv_variant")) {
+        if (value >= 0 && !Impl<double, double>::variant_available((int)value))
+            return fail(c, LAM_HIP_EINVAL, "gemv_variant %lld is a tuning shape: not in the product library (build `make tuning` and "
+                                           "load liblam_hip_tuning.so, see tools/gemv_probe.py)", (long long)value);
+        c->opt_gemv_variant = value;
+    }
     else if (!strcmp(name, "nt_loads")) c->opt_nt = value;
     else if (!strcmp(name, "force_generic")) c->opt_generic = value;
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
@@ -2345,6 +2400,7 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "fuse_update")) { c->opt_fuse = value; c->cg_ready = false; }
     else if (!strcmp(name, "symmetric")) { c->opt_symmetric = value; c->cg_ready = false; }   // other kernels, other partial arrays
     else if (!strcmp(name, "gemv_timing")) c->opt_gemv_timing = value < 0 ? 0 : value;
+    else if (!strcmp(name, "verify_direct")) c->opt_verify_direct = value;
     else if (!strcmp(name, "host_threads")) c->opt_host_threads = value;
     else if (!strcmp(name, "exchange_hub")) c->opt_hub = value;
     else if (!strcmp(name, "assume_cus")) { c->opt_assume_cus = value; c->cg_ready = false; }
@@ -2371,8 +2427,11 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "reuse_matrix")) *value = c->opt_reuse_matrix;
     else if (!strcmp(name, "fuse_update")) *value = c->opt_fuse;
     else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
+    else if (!strcmp(name, "tuning_variants")) *value = Impl<double, double>::variant_available(1) ? 1 : 0;
     else if (!strcmp(name, "fuse_effective")) *value = c->fuse_active ? 1 : 0;
     else if (!strcmp(name, "gemv_timing")) *value = c->opt_gemv_timing;
+    else if (!strcmp(name, "verify_direct")) *value = c->opt_verify_direct;
+    else if (!strcmp(name, "direct_fallbacks")) *value = c->direct_fallbacks;
     else if (!strcmp(name, "host_threads")) *value = c->opt_host_threads;
     else if (!strcmp(name, "exchange_hub")) *value = c->opt_hub;
     else if (!strcmp(name, "assume_cus")) *value = c->opt_assume_cus;

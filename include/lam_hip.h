@@ -84,6 +84,10 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
  * and distributed by the caller (MPI_Bcast, torch.distributed, a file ...), exactly the
  * bootstrap of ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:306-334 (ncclGetUniqueId + MPI_Bcast +
  * ncclCommInitRank, timed into the extra CSV column -> lam_hip_stats.t_comm_init). */
+/* RCCL prints a version banner to STDOUT when a communicator is created.  The library leaves the process's file
+ * descriptors alone by default; a caller whose stdout is a protocol (this package's drivers: one CSV line) sets the
+ * environment variable LAM_HIP_QUIET_RCCL=1, and file descriptor 1 then points at stderr for the duration of
+ * ncclCommInitRank (process-wide: other threads' stdout goes there too for that window). */
 int lam_hip_get_unique_id(void *unique_id_out);
 int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, int nranks,
                         const void *unique_id);
@@ -201,7 +205,11 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   ncclAllGather(p slices) -- sliced x, r, Ap, replicated p.  1: ONE ncclAllGather of
  *                   [Ap slice | p.Ap partial] per iteration, r and p kept full-length on every rank and
  *                   updated redundantly (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505); needs
- *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  2: DIRECT exchange, no
+ *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  2: DIRECT exchange
+ *                   (EXPERIMENTAL: pinned on one GPU with ranks as threads and as processes, never yet run on
+ *                   separate GPUs; lam_hip_solve therefore checks the recomputed residual against the recursive
+ *                   one afterwards and solves again on exchange 0 if they disagree -- options "verify_direct",
+ *                   "direct_fallbacks"), no
  *                   collective call inside the iteration: every rank maps the other ranks' p replicas and
  *                   mailboxes (HIP IPC; set up once per problem through the communicator) and the kernels store
  *                   their partial dot products and p slices straight into them over xGMI, tagged with the
@@ -219,6 +227,20 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *   "fuse_update"   one shard, and exchange 2: 1 (default) = the x, r and p updates of an iteration are ONE launch (the
  *                   r.r total is handed over inside the launch); with exchange 2 and overlap 0 that launch also waits
  *                   for the peers' p slices, so an iteration is two launches.  0 = two kernels.  Same bits either way.
+ *                   The fused launch's workgroups wait for each other, so it is used only when cg_init finds that
+ *                   the whole grid can be resident at once (occupancy x CU count; "fuse_effective" tells,
+ *                   "assume_cus" overrides the CU count for tests); otherwise the two-kernel form runs.
+ *   "gemv_timing"   T (default 8): a HIP-event pair brackets the GEMV of every T-th iteration (lam_hip_stats.t_gemv is
+ *                   their average); 1 = every iteration (costs ~8 us per iteration: each record is a marker packet
+ *                   between the kernels), 0 = never (t_gemv = 0).  The host follows the iteration through a progress
+ *                   word in pinned memory, not through events.
+ *   "host_threads"  one process, several shards: 1 = every shard is enqueued by a host thread of its own (the
+ *                   reference's OpenMP-thread-per-device shape); 0 (default) = one thread enqueues all shards.
+ *   "exchange_hub"  one process, more than two shards: 1 = the shards' streams meet at one join event per exchange
+ *                   (2P+1 runtime calls) instead of every stream waiting for every other one (P(P-1)); 0 (default).
+ *                   Measured host cost of both: profiles/r03_host_enqueue_cost.txt.  Same bits in every combination.
+ *   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "host_enqueue_ns" (get only): runtime calls issued and host
+ *                   time spent by the iteration loop so far (diagnostics, tools/host_enqueue_cost.py).
  *   "reuse_matrix"  1 (default) = lam_hip_set_problem keeps the matrix allocation when it is large enough for the new
  *                   problem (grow-only: a context never hands tens of GB back between problems); 0 = free + allocate.
  *   "upload_staging" lam_hip_upload_rows: 1 = copy through two pinned staging buffers (host memcpy overlapped
@@ -228,8 +250,11 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.  Exchange 2: 1 runs
  *                   that own-columns panel in front of the wait for the peers' p slices; 0 waits first and
  *                   launches the GEMV once.
- *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype; 0..22 = tuning shapes
- *                   (tools/gemv_probe.py; 19-22 are the MFMA experiment, LAM_HIP_BF16 only).
+ *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype (10 for fp64/fp32, 0 for bf16); 20 / 21 = the
+ *                   MFMA-fed bf16 GEMV (p rounded to bf16 / p exact as three bf16 terms; LAM_HIP_BF16 only; BASELINE
+ *                   configs[3]'s comparison, slower than the VALU kernel).  The other shapes (1-9, 11-19, 22) are tuning
+ *                   scaffolding: they exist only in the tuning build (`make tuning`, liblam_hip_tuning.so, used by
+ *                   tools/gemv_probe.py; "tuning_variants" tells) and are refused with LAM_HIP_EINVAL here.
  *   "nt_loads"      1 (default) = non-temporal loads for the matrix stream.
  *   "force_generic" 1 = always use the any-N scalar-load GEMV.
  *   "probe_rows"    lam_hip_gemv_only: use only the first ROWS rows of a shard (a P-way split's shape).

@@ -73,7 +73,7 @@ def main():
                 y = s.gemv(xprobe)               # collective
                 out[r] = dict(conv=conv, iters=s.stats["num_iters"], err=s.stats["rel_err"], x=x, res=res, y=y,
                               part=s.partition(r), ncoll=s.get_option("collectives_enqueued"), calls=calls,
-                              eff=s.get_option("exchange_effective"))
+                              eff=s.get_option("exchange_effective"), fallbacks=s.get_option("direct_fallbacks"))
         except Exception as e:                   # noqa: BLE001
             errs.append(f"rank {r}: {e!r}")
 
@@ -90,7 +90,7 @@ def main():
         "P": P, "n": n, "iters": out[0]["iters"], "converged": bool(out[0]["conv"]), "true_residual": out[0]["res"],
         "rel_err": out[0]["err"], "partition": [list(o["part"]) for o in out],
         "collectives_enqueued": [o["ncoll"] for o in out], "iterate_calls": [o["calls"] for o in out],
-        "exchange_effective": [o["eff"] for o in out], "x_sha": hashlib.sha256(out[0]["x"].tobytes()).hexdigest(),
+        "exchange_effective": [o["eff"] for o in out], "direct_fallbacks": [o["fallbacks"] for o in out], "x_sha": hashlib.sha256(out[0]["x"].tobytes()).hexdigest(),
         "ranks_identical": bool(all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"]
                                     and o["err"] == out[0]["err"] and np.array_equal(out[0]["y"], o["y"]) for o in out)),
     }

@@ -353,12 +353,12 @@ def test_cg_with_split_gemv_matches_unsplit(lam, oracle, n, lo, hi, generic):
 # ------------------------------------------------------------------------------------------------
 # MFMA experiment kernels for bf16 storage (gemv_variant 19-22): same answers as the VALU kernel
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant,tol", [(19, 32 * 2.0 ** -24), (21, 32 * 2.0 ** -24), (22, 32 * 2.0 ** -24),
-                                         (20, 2.0 ** -8)])
+@pytest.mark.parametrize("variant,tol", [(21, 32 * 2.0 ** -24), (20, 2.0 ** -8)])
 @pytest.mark.parametrize("n", [512, 4096, 4104, 9000])
 def test_mfma_bf16_gemv_matches_fp64(lam, variant, tol, n):
-    """Asymmetric random data, so a wrong fragment/diagonal map cannot cancel.  Variants 19/21/22 feed
-    p as three exact bf16 terms (fp32-faithful); variant 20 rounds p to bf16 (8 significant bits)."""
+    """Asymmetric random data, so a wrong fragment/diagonal map cannot cancel.  Variant 21 feeds
+    p as three exact bf16 terms (fp32-faithful); variant 20 rounds p to bf16 (8 significant bits).  (The two
+    other MFMA shapes, 19 and 22, are tuning shapes: test_tuning_build_variants.)"""
     A = _rand_matrix(n, n, n + 3).astype(np.float32)
     x = np.random.default_rng(n + 4).uniform(-1, 1, n).astype(np.float32)
     with lam.Solver(lam.BF16) as s:
@@ -682,3 +682,24 @@ def test_changing_the_product_kernel_needs_a_new_cg_init(lam):
                 s.cg_iterate(1, 0.0)
             s.cg_init()
             s.cg_iterate(3, 0.0)
+
+
+def test_tuning_build_variants(lam):
+    """The GEMV shapes that are nobody's default live in the tuning build only (liblam_hip_tuning.so, `make tuning`):
+    the product library refuses them, and the tuning build computes the same products with every one of them
+    (tools/gemv_probe.py --check, its own process because it loads the other library)."""
+    import subprocess
+    import sys
+    with lam.Solver(lam.F64) as s:
+        assert s.get_option("tuning_variants") == 0
+        for v in (1, 9, 13, 18, 19, 22):
+            with pytest.raises(lam.LamHipError):
+                s.set_option("gemv_variant", v)
+        for v in (-1, 0, 10):
+            s.set_option("gemv_variant", v)
+    probe = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "gemv_probe.py")
+    for dtype, variants in (("f64", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18"), ("f32", "0,8,9,10,12,15,18"),
+                            ("bf16", "0,1,10,19,20,21,22")):
+        r = subprocess.run([sys.executable, probe, "4104", "8192", "--check", "--dtype", dtype, "--variants", variants],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count(" ok") == 2 * len(variants.split(",")), r.stdout + r.stderr[-2000:]

@@ -210,6 +210,22 @@ def test_async_mock_catches_timing_dependent_stop(mock_async, tmp_path):
     pytest.skip("the timing-dependent stop did not desynchronise the ranks in three tries on this box")
 
 
+def test_direct_exchange_solve_checks_itself_and_falls_back(mock_async, tmp_path):
+    """lam_hip_solve on the direct exchange recomputes the residual afterwards (all ranks get the same number); when it
+    does not match the recursion -- here because one rank's p replica is perturbed in iteration 3, what a stale read of
+    a peer's slice would amount to -- every rank solves again on the RCCL exchange and the caller gets the right
+    answer, with the event counted (exchange 2 is experimental until it has run on real peers)."""
+    r, out, lines = _run(mock_async, tmp_path, 4, 4096, "spd", "--exchange", 2, env_extra={"LAM_HIP_DEBUG_DIRECT_STALE": "2"})
+    _check_mock_stats(lines, 4)
+    _check_solution(out, 4, 4096, "spd")
+    assert out["direct_fallbacks"] == [1, 1, 1, 1] and out["exchange_effective"] == [0, 0, 0, 0]
+    assert "does not match the recursive residual" in r.stderr
+    # without the fault: no fallback, the direct exchange stays in use
+    r, out, lines = _run(mock_async, tmp_path, 4, 4096, "spd", "--exchange", 2)
+    _check_solution(out, 4, 4096, "spd")
+    assert out["direct_fallbacks"] == [0, 0, 0, 0] and out["exchange_effective"] == [2, 2, 2, 2]
+
+
 # ---- multi-process: the driver's exact torchrun command ------------------------------------------------
 def _bench_torchrun(mock, nproc, tmp_path, extra_env=None):
     env = dict(os.environ, LD_PRELOAD=mock, GPU_MAX_HW_QUEUES="8", MOCK_RCCL_STATS_FILE=os.path.join(str(tmp_path), "st.jsonl"))

@@ -87,3 +87,44 @@ def test_rendezvous_times_out_when_a_rank_never_arrives(tmp_path):
     env.update(RANK="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
     assert "TIMEOUT" in r.stdout, r.stdout + r.stderr
+
+
+def test_rendezvous_survives_strangers(tmp_path):
+    """Connections that are not ranks -- one that sends a non-numeric hello with the right framing, one that sends
+    an absurd length, one that says nothing -- must not take rank 0 down or hold its accept loop: the real rank
+    that arrives afterwards still gets in, well before the rendezvous timeout."""
+    import socket
+    import struct
+    import time
+    path = str(tmp_path / "rdzv")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMI_RANK", "PMI_SIZE")}
+    env.update(WORLD_SIZE="2", LAM_RDZV_FILE=path)
+    p0 = subprocess.Popen([sys.executable, "-c", WORKER], env=dict(env, RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not os.path.exists(path):
+        assert time.time() - t0 < 30 and p0.poll() is None
+        time.sleep(0.02)
+    assert oct(os.stat(path).st_mode & 0o777) == "0o600"           # created for this user only
+    port, nonce = open(path).read().split()
+    strangers = []
+    for payload in (struct.pack("<Q", 9) + b"abc " + nonce[:5].encode(), struct.pack("<Q", 1 << 60), b""):
+        c = socket.create_connection(("127.0.0.1", int(port)), timeout=5)
+        if payload:
+            c.sendall(payload)
+        strangers.append(c)
+    bad = f"x {nonce}".encode()                                   # right nonce, rank field not a number
+    c = socket.create_connection(("127.0.0.1", int(port)), timeout=5)
+    c.sendall(struct.pack("<Q", len(bad)) + bad)
+    strangers.append(c)
+    p1 = subprocess.Popen([sys.executable, "-c", WORKER], env=dict(env, RANK="1", LOCAL_RANK="1"), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True)
+    outs = []
+    for p in (p0, p1):
+        so, se = p.communicate(timeout=60)
+        assert p.returncode == 0, se
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    for c in strangers:
+        c.close()
+    assert time.time() - t0 < 40
+    assert [o["rank"] for o in outs] == [0, 1] and all(o["blob_ok"] and o["size"] == 2 for o in outs)
