@@ -2033,7 +2033,9 @@ int lam_hip_solve(lam_hip_ctx *c, int max_iters, double rel_error, lam_hip_stats
         // attainable accuracy of the dtype.  On a mismatch the system is solved again on the RCCL exchange.
         double tr = 0.0;
         LAMCHK(lam_hip_true_residual(c, &tr));
-        const double slack = 100.0 * std::sqrt(c->dtype == LAM_HIP_F64 ? 2.220446049250313e-16 : 5.9604644775390625e-08);
+        // room for what the recursion legitimately drifts by (~ eps x cond): 1e6 eps in fp64, 1e-4 with fp32 vectors;
+        // a false alarm costs one more solve, a miss costs a wrong answer
+        const double slack = c->dtype == LAM_HIP_F64 ? 2.2e-10 : 1e-4;
         if (!(tr <= 10.0 * local.rel_err + slack)) {
             if (c->rank == 0)
                 fprintf(stderr, "lam_hip: direct exchange: recomputed residual %.3e does not match the recursive residual %.3e -- "
