@@ -482,6 +482,8 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
             const uint32_t nv = cols / PV;
             for (uint32_t i = tid; i < nv; i += kBlock) dst[i] = src[i];
             for (uint32_t i = nv * PV + tid; i < cols; i += kBlock) s_p[i] = a.p[c0 + i];
+            // ragged tile: zeros up to the next whole wave step (what the lanes past the end multiply with)
+            for (uint32_t i = cols + tid; i < (uint32_t)TILE && i < (cols + STEP - 1) / STEP * STEP; i += kBlock) s_p[i] = (TV)0;
         }
         __syncthreads();
         }
@@ -505,49 +507,31 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
                     for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
             }
         } else {
-            // ragged last tile: whole wave steps with the streaming body, then the bounds-checked remainder
-            const int full = (int)(cols / STEP);
-            int sfull = 0;
-#pragma unroll 1
-            for (; sfull + UNROLL <= full; sfull += UNROLL) {
-                avec_t av[UNROLL][R];
+            // Ragged last tile of a segment (N not a multiple of TILE: 18 % of the columns at N=10000): the SAME
+            // streaming body over ceil(cols / STEP) steps.  Lanes past the end of the segment read the row's last
+            // vector again (address clamped: in bounds) against a ZERO of p -- the p tile is zero-filled behind `cols`
+            // (LDS) or the product is masked (p from L2) -- so they add +-0 and the sums keep their bits.  No second
+            // code path with its own registers: round 2's separately unrolled ragged body doubled the kernels' VGPRs
+            // (fp32 54 -> 98, bf16 104 -> 256: occupancy 8 -> 4 and 4 -> 1) and the full-tile path paid for it.
+            const int nsteps = (int)((cols + STEP - 1) / STEP);
+            const uint32_t last = cols - VEC;                 // cols is a multiple of VEC (>= VEC)
+#pragma unroll UNROLL
+            for (int s = 0; s < nsteps; s++) {
+                const uint32_t col = (uint32_t)s * STEP + (uint32_t)lane * VEC;
+                const uint32_t colc = col < last ? col : last;
+                avec_t av[R];
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * STEP);
-                        av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
-                    }
-#pragma unroll
-                for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-#pragma unroll
-                        for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * pt[(sfull + u) * STEP + lane * VEC + i];
-            }
-            {   // fewer than UNROLL whole steps + a partial one: one predicated group, loads in flight together
-                avec_t av[UNROLL][R];
-                bool on[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; u++) {
-                    const uint32_t c = (uint32_t)(sfull + u) * STEP + lane * VEC;
-                    on[u] = c < cols;
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (on[u]) {
-                            const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * STEP);
-                            av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
-                        }
-                    }
+                for (int r = 0; r < R; r++) {
+                    const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] - (uint64_t)lane * VEC + c0 + colc);
+                    av[r] = NT ? __builtin_nontemporal_load(src) : *src;
                 }
+                TV pv[VEC];
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++)
-                    if (on[u]) {
+                for (int i = 0; i < VEC; i++) pv[i] = USE_LDS ? pt[col + i] : (col < cols ? pt[col + i] : (TV)0);
 #pragma unroll
-                        for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++)
 #pragma unroll
-                            for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * pt[(sfull + u) * STEP + lane * VEC + i];
-                    }
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
             }
         }
         tt = (tt + 1 == ntiles) ? 0 : tt + 1;
@@ -638,6 +622,9 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
             const uint32_t nv = cols / PV;
             for (uint32_t i = tid; i < nv; i += NTHREADS) dst[i] = src[i];
             for (uint32_t i = nv * PV + tid; i < cols; i += NTHREADS) s_p[i] = a.p[c0 + i];
+            // ragged tile: zeros up to the next whole super-step (what the lanes past the end multiply with)
+            for (uint32_t i = cols + tid; i < (uint32_t)TILE && i < (cols + STEP * WAVES - 1) / (STEP * WAVES) * (STEP * WAVES); i += NTHREADS)
+                s_p[i] = (TV)0;
         }
         __syncthreads();
         if (cols == TILE) {
@@ -658,52 +645,28 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
                     for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
             }
         } else {
-            // ragged last tile of a segment (N not a multiple of TILE: 18 % of the columns at N=10000): the same
-            // streaming body over its whole super-steps, then one bounds-checked vector per lane
-            const int full = (int)(cols / (STEP * WAVES));
-            int sfull = 0;
-#pragma unroll 1
-            for (; sfull + UNROLL <= full; sfull += UNROLL) {
-                avec_t av[UNROLL][R];
+            // ragged last tile of a segment: the same streaming body over ceil(cols / super-step) super-steps; lanes past
+            // the end re-read the row's last vector (clamped address) against the zeros the staging put behind `cols`,
+            // so they add +-0 (see gemv_tile_kernel: no second unrolled body, no second set of registers)
+            const int nsteps = (int)((cols + STEP * WAVES - 1) / (STEP * WAVES));
+            const uint32_t last = cols - VEC;
+#pragma unroll UNROLL
+            for (int s = 0; s < nsteps; s++) {
+                const uint32_t col = (uint32_t)s * (STEP * WAVES) + woff;
+                const uint32_t colc = col < last ? col : last;
+                avec_t av[R];
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * (STEP * WAVES));
-                        av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
-                    }
-#pragma unroll
-                for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-#pragma unroll
-                        for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * s_p[(sfull + u) * (STEP * WAVES) + woff + i];
-            }
-            // what is left is fewer than UNROLL whole super-steps plus a partial one: one predicated group,
-            // all of its loads in flight together (a step-at-a-time loop here is a chain of HBM latencies)
-            {
-                avec_t av[UNROLL][R];
-                bool on[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; u++) {
-                    const uint32_t c = (uint32_t)(sfull + u) * (STEP * WAVES) + woff;
-                    on[u] = c < cols;                  // cols and woff are multiples of VEC: all of the vector or none
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (on[u]) {
-                            const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)(sfull + u) * (STEP * WAVES));
-                            av[u][r] = NT ? __builtin_nontemporal_load(src) : *src;
-                        }
-                    }
+                for (int r = 0; r < R; r++) {
+                    const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] - woff + c0 + colc);
+                    av[r] = NT ? __builtin_nontemporal_load(src) : *src;
                 }
+                TV pv[VEC];
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++)
-                    if (on[u]) {
+                for (int i = 0; i < VEC; i++) pv[i] = s_p[col + i];
 #pragma unroll
-                        for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++)
 #pragma unroll
-                            for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[u][r], i) * s_p[(sfull + u) * (STEP * WAVES) + woff + i];
-                    }
+                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
             }
         }
         tt = (tt + 1 == ntiles) ? 0 : tt + 1;

@@ -98,13 +98,25 @@ def cpu_baseline(sample_n, iters):
             "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
 
 
-def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False, generate=True):
+def clock_ramp(s, seconds):
+    """Untimed set-up, like the matrix generation: keep the device busy with GEMV launches for `seconds` before the
+    warm-up steps.  An MI355X that has just been idle serves the first ~0.3 s of sustained load at a lower memory-clock
+    level (same launch: 5.02 ms, later 4.815 ms -- profiles/r03_clock_ramp.txt); a timed region of 0.1-0.5 s that
+    starts 60 ms after the first touch would measure that transient, not the rate a solve runs at."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        s.gemv_only(10)
+
+
+def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False, generate=True, ramp_s=0.0):
     """W untimed + K timed CG iterations on solver `s`.  The context keeps its matrix allocation when N
     shrinks (grow-only), so several configurations can follow each other in one process without a large
     hipFree in between ("allocation history")."""
     if generate:
         s.generate_random_spd(n, seed, cond)
         s.generate_random_rhs(seed + 1)
+    if ramp_s > 0:
+        clock_ramp(s, ramp_s)
     s.set_option("symmetric", 1 if symmetric else 0)
     if symmetric and s.get_option("symmetric_effective") != 1:
         raise RuntimeError("option 'symmetric' is not available for this configuration")
@@ -187,6 +199,8 @@ def main():
                     help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes (roofline.traffic then "
                     "comes from profiles/traffic.json, tagged as such)")
+    ap.add_argument("--ramp", type=float, default=0.6, help="seconds of untimed GEMV launches before the warm-up steps of the headline "
+                    "(device clock ramp, see clock_ramp); 0 = none")
     ap.add_argument("--config4-n", type=int, default=131072, help="matrix order of the configs[3] GEMV-only side run")
     ap.add_argument("--cpu-sample-n", type=int, default=32768)
     ap.add_argument("--cpu-sample-iters", type=int, default=10)
@@ -253,7 +267,7 @@ def main():
     # HEADLINE = the product's default configuration of this topology (rank mode: lam_hip's default exchange), whatever
     # the other exchange modes measure below; they are recorded under "exchange_modes" only.
     default_exchange = s.get_option("exchange") if use_dist else None
-    st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric)
+    st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric, ramp_s=args.ramp)
     kernel_name = s.gemv_kernel_name()
 
     def max_over_ranks(dt_, st_):
@@ -433,6 +447,7 @@ def main():
                     s4.generate_random_spd(n4, 1234, 1e4)
                     s4.generate_random_rhs(1235)
                     s4.cg_init()                              # p = b: a real vector in the GEMV's p replica
+                    clock_ramp(s4, 0.3)
                     for v4, what4 in variants:
                         s4.set_option("gemv_variant", v4)
                         ts = sorted(s4.gemv_only(10) for _ in range(3))
@@ -460,6 +475,8 @@ def main():
         "config": {"workload": f"dense SPD CG, N={n} fp64 (BASELINE configs[2]), device-generated random "
                                f"SPD matrix (cond 1e6) + random rhs, {args.steps} fixed iterations",
                    "n": n, "parallelism": parallelism,
+                   "untimed_setup": f"matrix generated on the device; {args.ramp} s of GEMV launches before the warm-up steps "
+                                    "(device clock ramp, profiles/r03_clock_ramp.txt)",
                    "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
         "gemv_ms": st["t_gemv"] * 1e3,
         "other_us": (ms_per_step - st["t_gemv"] * 1e3) * 1e3,
