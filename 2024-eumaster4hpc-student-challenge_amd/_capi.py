@@ -53,6 +53,21 @@ def build(force=False):
 _lib = None
 
 
+def source_id():
+    """sha256 prefix of the sources the library is built from (same recipe as the Makefile's SRC_ID), or None when the
+    sources are not next to the package."""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for f in (os.path.join(_HERE, "csrc", "lam_hip.hip"), os.path.join(_HERE, "csrc", "lam_kernels.h"),
+                  os.path.join(os.path.dirname(_HERE), "include", "lam_hip.h")):
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Load the HIP library.  Fails loudly if it is missing: there is no fallback path."""
     global _lib
@@ -64,6 +79,7 @@ def lib():
         vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
         sig = {
             "lam_hip_abi_version": ([], i32),
+            "lam_hip_build_id": ([], C.c_char_p),
             "lam_hip_device_count": ([C.POINTER(i32)], i32),
             "lam_hip_create": ([C.POINTER(vp), i32, i32, C.POINTER(i32)], i32),
             "lam_hip_get_unique_id": ([vp], i32),
@@ -103,6 +119,10 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export it
             fn.argtypes, fn.restype = args, res
         L._lam_symbols = tuple(sig)
+        built, want = L.lam_hip_build_id().decode(), source_id()
+        if want is not None and built != want and not os.environ.get("LAM_HIP_ALLOW_STALE"):
+            raise ImportError(f"{_LIB} was built from other sources (library {built}, sources {want}): rebuild it "
+                              f"(`make -C {_HERE} all tuning` or __graft_entry__.build())")
         _lib = L
     return _lib
 

@@ -1462,6 +1462,11 @@ extern "C" {
 
 int lam_hip_abi_version(void) { return LAM_HIP_ABI_VERSION; }
 
+#ifndef LAM_SOURCE_ID
+#define LAM_SOURCE_ID "unknown"
+#endif
+const char *lam_hip_build_id(void) { return LAM_SOURCE_ID; }
+
 int lam_hip_device_count(int *count)
 {
     if (!count) return LAM_HIP_EINVAL;

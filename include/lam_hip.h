@@ -68,6 +68,10 @@ typedef struct lam_hip_stats {
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 
 int lam_hip_abi_version(void);
+/* 16 hex digits identifying the sources (csrc/lam_hip.hip, csrc/lam_kernels.h, this header) the library was built
+ * from (sha256 prefix, set by the Makefile).  The Python binding compares it with the sources next to it and refuses
+ * a stale library.  No reference counterpart. */
+const char *lam_hip_build_id(void);
 int lam_hip_device_count(int *count);
 
 /* One process driving `n_shards` row shards, shard q on device_ids[q] (device ids may repeat,

@@ -3,6 +3,8 @@ symbol include/lam_hip.h declares, and refuses to compute without a GPU (no CPU 
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 from conftest import ROOT
 
@@ -105,3 +107,20 @@ def test_file_header_rule_is_the_same_in_cpp_and_python(lam, tmp_path):
         except OSError:
             got_py = None
         assert got_cpp == want and got_py == want, (name, got_cpp, got_py, want)
+
+
+def test_stale_library_is_refused(lam):
+    """The library carries the identity of the sources it was built from (lam_hip_build_id, set by the Makefile); the
+    binding compares it with the sources next to it, so a .so left over from an earlier edit can never pass for the
+    current code (round 3: a silently failed rebuild had a whole GPU test run exercise the previous kernels)."""
+    import importlib
+    capi = importlib.import_module(lam.__name__ + "._capi")
+    assert lam.lib().lam_hip_build_id().decode() == capi.source_id()
+    code = ("import importlib, sys\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            f"capi = importlib.import_module({lam.__name__!r} + '._capi')\n"
+            "capi.source_id = lambda: '0123456789abcdef'\n"
+            "try:\n    capi.lib(); print('LOADED')\n"
+            "except ImportError as e:\n    print('REFUSED', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "REFUSED" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr
