@@ -88,6 +88,13 @@ struct ShardBase {
     hipEvent_t ev_g2[kLag] = {}, ev_g3[kLag] = {};              // second panel of a split GEMV
     bool split_slot[kLag] = {};
     bool timed_slot[kLag] = {};                                 // the slot's iteration recorded its timing events
+    // in-launch hand-over / direct exchange (lam_kernels.h, Mail): the shard's mailbox (fine-grained device memory where
+    // the runtime offers it), the broadcast lines of its fused update launch, and the iteration whose fused launch has
+    // already waited for the peers' p slices.  Kept for the life of the context.
+    Mail *mail = nullptr;
+    bool mail_coarse = false;
+    BcastLine *bcast = nullptr;
+    int waited_k = 0;
 };
 
 }  // namespace
@@ -115,7 +122,6 @@ struct lam_hip_ctx {
     int64_t opt_symmetric = 0;     // single shard: read only the upper triangle (caller asserts A == A^T)
     int64_t opt_exchange = 0;      // rank mode: 0 = all-gather x2 (8 B/rank) + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
     int64_t opt_fuse = 1;          // one shard / direct exchange: x, r and p updates in ONE launch (update_fused_kernel)
-    int waited_k = 0;              // direct exchange: the iteration whose fused launch already waited for the peers' p slices
     int64_t opt_reuse_matrix = 1;  // lam_hip_set_problem keeps (and re-uses) the matrix allocation when it is large enough
     int64_t opt_upload_staging = 0; // lam_hip_upload_rows: 1 = pipeline through two pinned staging buffers
     int64_t opt_finalize = 1;      // several shards: 1 = producer kernels reduce their partials themselves (Finalize);
@@ -141,11 +147,8 @@ struct lam_hip_ctx {
     uint64_t enqueue_ns = 0;       // host time spent issuing iterations (the waits for the device's progress excluded)
     std::mutex err_mu;             // `err` may be written by the per-shard enqueue threads
     // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
-    Mail *mail = nullptr;                       // own mailbox, fine-grained device memory
-    bool mail_coarse = false;                   // ... or ordinary device memory (enough for one shard, not for peers)
-    BcastLine *bcast = nullptr;                 // [2][kBcastLines] in-launch broadcast lines of update_fused_kernel (ordinary device memory)
-    Mail *peer_mail[kMaxShards] = {};           // every rank's mailbox as seen from here (own included)
-    void *peer_p[kMaxShards] = {};              // every rank's p replica as seen from here (own included)
+    Mail *peer_mail[kMaxShards] = {};           // every shard's mailbox as seen from this process (own included)
+    void *peer_p[kMaxShards] = {};              // every shard's p replica as seen from this process (own included)
     void *ipc_opened[2 * kMaxShards] = {};      // mappings to close again
     int n_ipc_opened = 0;
     uint64_t problem_gen = 0, direct_gen = ~0ull;   // direct mappings belong to one set_problem generation
@@ -167,7 +170,7 @@ struct lam_hip_ctx {
     }
 
     // gather-Ap needs equal slices and an 8-byte aligned tail for the double
-    bool exchange2_wanted() const { return rank_mode && opt_exchange == 2 && opt_finalize != 0; }
+    bool exchange2_wanted() const { return (rank_mode || total_shards > 1) && opt_exchange == 2 && opt_finalize != 0; }
     bool exchange1_ok() const
     {
         return rank_mode && opt_exchange == 1 && n % (uint64_t)nranks == 0 && ((n / (uint64_t)nranks) * esz_v()) % 8 == 0;
@@ -642,7 +645,7 @@ int create_common(lam_hip_ctx *c)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
     }
     // the error word of the bounded in-kernel waits (reducer workgroups, fused update, direct exchange)
-    if (hipSetDevice(c->sh[0].dev) != hipSuccess || hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocDefault) != hipSuccess)
+    if (hipSetDevice(c->sh[0].dev) != hipSuccess || hipHostMalloc((void **)&c->direct_err, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
         return fail(nullptr, LAM_HIP_EHIP, "hipHostMalloc (error word) failed");
     memset(c->direct_err, 0, 64);
     // peer access between distinct devices of one process (direct xGMI stores)
@@ -913,25 +916,26 @@ MailPost no_post()
 // The context's mailbox (lam_kernels.h, Mail) and the pinned error word of the bounded waits.  Fine-grained
 // (uncached) memory where the runtime offers it: in the direct exchange it is polled by this rank's kernels
 // while peers write it over xGMI; with one shard only the launch's own reducer workgroup writes it.
-int ensure_mail(lam_hip_ctx *c, bool *got_finegrained)
+int ensure_mail(lam_hip_ctx *c, ShardBase &s, bool *got_finegrained)
 {
     if (got_finegrained) *got_finegrained = true;
-    if (c->mail == nullptr) {
-        if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocUncached) != hipSuccess) {
+    LAMCHK(set_dev(c, s));
+    if (s.mail == nullptr) {
+        if (hipExtMallocWithFlags((void **)&s.mail, sizeof(Mail), hipDeviceMallocUncached) != hipSuccess) {
             (void)hipGetLastError();
-            if (hipExtMallocWithFlags((void **)&c->mail, sizeof(Mail), hipDeviceMallocFinegrained) != hipSuccess) {
+            if (hipExtMallocWithFlags((void **)&s.mail, sizeof(Mail), hipDeviceMallocFinegrained) != hipSuccess) {
                 (void)hipGetLastError();
-                c->mail = nullptr;
-                c->mail_coarse = true;
-                HIPCHK(c, hipMalloc((void **)&c->mail, sizeof(Mail)));
+                s.mail = nullptr;
+                s.mail_coarse = true;
+                HIPCHK(c, hipMalloc((void **)&s.mail, sizeof(Mail)));
             }
         }
-        HIPCHK(c, hipMemset(c->mail, 0, sizeof(Mail)));
+        HIPCHK(c, hipMemset(s.mail, 0, sizeof(Mail)));
     }
-    if (got_finegrained) *got_finegrained = !c->mail_coarse;
-    if (c->bcast == nullptr) {
-        HIPCHK(c, hipMalloc((void **)&c->bcast, 2 * kBcastLines * sizeof(BcastLine)));
-        HIPCHK(c, hipMemset(c->bcast, 0, 2 * kBcastLines * sizeof(BcastLine)));
+    if (got_finegrained) *got_finegrained = !s.mail_coarse;
+    if (s.bcast == nullptr) {
+        HIPCHK(c, hipMalloc((void **)&s.bcast, 2 * kBcastLines * sizeof(BcastLine)));
+        HIPCHK(c, hipMemset(s.bcast, 0, 2 * kBcastLines * sizeof(BcastLine)));
     }
     return 0;
 }
@@ -956,8 +960,42 @@ struct DirectHello {
 
 // Collective: every rank must call it the same number of times (it is part of lam_hip_cg_init).  Ends
 // with an agreement, so either all ranks use the direct exchange or none does.
+// One process, several shards: the same exchange without any mapping step -- all shards live in this address space and
+// peer access between their devices was enabled when the context was created.  The kernels of one shard wait (bounded)
+// for stores made by the kernels of the other shards, so every shard's stream must be able to make progress on its own:
+// guaranteed when every shard has a device of its own; shards that SHARE a device could sit behind each other in one
+// hardware queue (a waiting kernel in front of the kernel it waits for), so that layout gets the direct exchange only on
+// request (LAM_HIP_DIRECT_SAME_DEVICE=1: tests, with GPU_MAX_HW_QUEUES >= number of shards) and the event exchange otherwise.
+int setup_direct_local(lam_hip_ctx *c)
+{
+    if (c->direct_gen == c->problem_gen) return 0;
+    close_direct(c);
+    bool ok = true;
+    if (const char *off = getenv("LAM_HIP_DIRECT_DISABLE"))
+        if (*off && strcmp(off, "0") != 0) ok = false;
+    bool shared = false;
+    for (auto &s : c->sh)
+        for (auto &t : c->sh)
+            if (&s != &t && s.dev == t.dev) shared = true;
+    if (shared) {
+        const char *same = getenv("LAM_HIP_DIRECT_SAME_DEVICE");
+        if (!(same && *same && strcmp(same, "0") != 0)) ok = false;
+    }
+    for (auto &s : c->sh) {
+        bool fine = false;
+        LAMCHK(ensure_mail(c, s, &fine));
+        if (!fine) ok = false;                  // peers must not poll-and-write ordinary (cached) memory
+        c->peer_p[s.index] = s.p;
+        c->peer_mail[s.index] = s.mail;
+    }
+    c->direct_ok = ok;
+    c->direct_gen = c->problem_gen;
+    return 0;
+}
+
 int setup_direct(lam_hip_ctx *c)
 {
+    if (!c->rank_mode) return setup_direct_local(c);
     if (c->direct_gen == c->problem_gen) return 0;
     close_direct(c);
     ShardBase &s = c->sh[0];
@@ -967,7 +1005,7 @@ int setup_direct(lam_hip_ctx *c)
         if (*off && strcmp(off, "0") != 0) ok = false;            // must then fall back together (tests; a kill switch)
     {
         bool fine = false;
-        LAMCHK(ensure_mail(c, &fine));
+        LAMCHK(ensure_mail(c, s, &fine));
         if (!fine) ok = false;                  // peers must not poll-and-write ordinary (cached) memory
     }
     const int P = c->nranks;
@@ -982,8 +1020,8 @@ int setup_direct(lam_hip_ctx *c)
     me.pid = (int)getpid();
     me.dev = s.dev;
     me.p = s.p;
-    me.mail = c->mail;
-    me.have_handles = ok && hipIpcGetMemHandle(&me.hp, s.p) == hipSuccess && hipIpcGetMemHandle(&me.hm, c->mail) == hipSuccess;
+    me.mail = s.mail;
+    me.have_handles = ok && hipIpcGetMemHandle(&me.hp, s.p) == hipSuccess && hipIpcGetMemHandle(&me.hm, s.mail) == hipSuccess;
     (void)hipGetLastError();
     memcpy(host.data() + kRec * (size_t)c->rank, &me, sizeof me);
     HIPCHK(c, hipMemcpyAsync((char *)dev.p + kRec * (size_t)c->rank, host.data() + kRec * (size_t)c->rank, kRec, hipMemcpyHostToDevice, s.stream));
@@ -994,7 +1032,7 @@ int setup_direct(lam_hip_ctx *c)
     for (int q = 0; q < P && ok; q++) {
         DirectHello h;
         memcpy(&h, host.data() + kRec * (size_t)q, sizeof h);
-        if (q == c->rank) { c->peer_p[q] = s.p; c->peer_mail[q] = c->mail; continue; }
+        if (q == c->rank) { c->peer_p[q] = s.p; c->peer_mail[q] = s.mail; continue; }
         if (h.mail == nullptr) { ok = false; break; }
         if (h.pid == me.pid) {
             // a thread of this process: same address space; another device needs peer access
@@ -1050,14 +1088,15 @@ bool fused_launch_resident(lam_hip_ctx *c, const ShardBase &s, int blocks)
     return (int64_t)std::min(per_cu, 8) * (int64_t)cus >= (int64_t)blocks;
 }
 
-int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
+// One shard's iteration on the direct exchange: rank mode has one local shard (index = rank); one process with several
+// shards enqueues them one after the other -- no event, no stream wait, no collective: 2-4 launches per shard.
+template <typename I>
+int enqueue_shard_direct(lam_hip_ctx *c, ShardBase &s, int k, double rel_error, int slot)
 {
-    return dispatch(c, [&](auto impl) -> int {
-        using I = decltype(impl);
         using TV = typename ImplTraits<I>::TV;
-        ShardBase &s = c->sh[0];
         LAMCHK(set_dev(c, s));
-        const int P = c->nranks;
+        const int P = c->total_shards;
+        const int me = s.index;
         const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
         // 1. GEMV.  p for this iteration: the own slice is local; the others were stored into this rank's
         //    replica by the peers' update_p of iteration k-1 (k == 1: by cg_init) -- wait for their flags
@@ -1069,7 +1108,7 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         if (P > 1 && c->opt_overlap && (!I::fast_ok(c) || (a % I::VEC == 0 && b % I::VEC == 0))) { lo = a; hi = b; }
         Finalize fa = no_finalize(c);
         fa.active = 1; fa.mail = 1; fa.seq = seq; fa.slot = 0; fa.dst.n = P;
-        for (int q = 0; q < P; q++) fa.dst.p[q] = &c->peer_mail[q]->pap[c->rank];
+        for (int q = 0; q < P; q++) fa.dst.p[q] = &c->peer_mail[q]->pap[me];
         BlockCounts nb;
         for (int q = 0; q < kMaxShards; q++) {
             uint64_t r0 = 0, nr = 0;
@@ -1080,12 +1119,12 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         // iteration 3, which is what a stale read of a peer's slice would amount to: the ranks stay in step, the result
         // is wrong, and lam_hip_solve's residual check must notice and solve again on the RCCL exchange.  Never set it otherwise.
         static const char *stale = getenv("LAM_HIP_DEBUG_DIRECT_STALE");
-        if (stale && *stale && atoi(stale) == c->rank && k == 3) {
+        if (stale && *stale && atoi(stale) == me && k == 3) {
             hipLaunchKernelGGL((axpby_kernel<TV>), dim3(vec_grid(c->n)), dim3(kBlock), 0, s.stream, (TV)0, (const TV *)s.p, (TV)1.001, (TV *)s.p, c->n);
             LAUNCHED(c);
         }
         // the fused update launch of iteration k-1 may have waited for the slices already (its waiter workgroup)
-        const bool need_wait = P > 1 && k > 1 && c->waited_k != k - 1;
+        const bool need_wait = P > 1 && k > 1 && s.waited_k != k - 1;
         const bool timed = timed_iteration(c, s, k);
         s.split_slot[slot] = hi > lo;
         s.timed_slot[slot] = timed;
@@ -1095,7 +1134,7 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
             if (timed) RECORD(c, s.ev_g1[slot], s.stream);
         }
         if (need_wait) {
-            hipLaunchKernelGGL(wait_p_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const Mail *)c->mail, P, c->rank, nb, seq - 1,
+            hipLaunchKernelGGL(wait_p_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const Mail *)s.mail, P, me, nb, seq - 1,
                                (const CgScalars *)s.sc, c->direct_err);
             LAUNCHED(c);
         }
@@ -1110,7 +1149,7 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
         }
         // 2. x, r: waits in the kernel for the P partials of p.Ap; its reducer posts the r.r partial
         Finalize fb = fa;
-        for (int q = 0; q < P; q++) fb.dst.p[q] = &c->peer_mail[q]->rr[c->rank];
+        for (int q = 0; q < P; q++) fb.dst.p[q] = &c->peer_mail[q]->rr[me];
         if (c->fuse_active) {
             // steps 2 and 3 in ONE launch; without an own-slice panel (overlap 0) a waiter workgroup also holds the
             // launch open until the peers' slices for the next GEMV are in: 2 launches per iteration
@@ -1118,40 +1157,48 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
             plf.n = P;
             for (int q = 0; q < P; q++) plf.p[q] = c->peer_p[q];
             MailPost postf = no_post();
-            postf.n = P; postf.rank = c->rank; postf.seq = seq;
+            postf.n = P; postf.rank = me; postf.seq = seq;
             for (int q = 0; q < P; q++) postf.mail[q] = c->peer_mail[q];
             static const char *dropf = getenv("LAM_HIP_DEBUG_DIRECT_DROP");
-            if (dropf && *dropf && atoi(dropf) == c->rank && k == 3) postf.seq = ~0ull;      // test hook, see below
+            if (dropf && *dropf && atoi(dropf) == me && k == 3) postf.seq = ~0ull;      // test hook, see below
             const bool waiter = P > 1 && !(hi > lo);
             hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1 + (waiter ? 1 : 0)), dim3(kBlock), 0, s.stream,
                                (const double *)nullptr, 0, s.sc, k, rel_error, (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x,
-                               (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fb, MailWait{c->mail->pap, P, seq, c->direct_err},
-                               MailWait{c->mail->rr, P, seq, c->direct_err}, c->bcast, plf, s.row0, (volatile int *)s.host_flags, postf,
-                               (const Mail *)c->mail, nb);
+                               (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fb, MailWait{s.mail->pap, P, seq, c->direct_err},
+                               MailWait{s.mail->rr, P, seq, c->direct_err}, s.bcast, plf, s.row0, (volatile int *)s.host_flags, postf,
+                               (const Mail *)s.mail, nb);
             LAUNCHED(c);
-            if (waiter) c->waited_k = k;
+            if (waiter) s.waited_k = k;
             return 0;
         }
         hipLaunchKernelGGL((update_xr_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
                            (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, fb,
-                           MailWait{c->mail->pap, P, seq, c->direct_err});
+                           MailWait{s.mail->pap, P, seq, c->direct_err});
         LAUNCHED(c);
         // 3. stop test + p slice into every replica + flags
         PtrList pl;
         pl.n = P;
         for (int q = 0; q < P; q++) pl.p[q] = c->peer_p[q];
         MailPost post = no_post();
-        post.n = P; post.rank = c->rank; post.seq = seq;
+        post.n = P; post.rank = me; post.seq = seq;
         for (int q = 0; q < P; q++) post.mail[q] = c->peer_mail[q];
         // LAM_HIP_DEBUG_DIRECT_DROP=<rank>: test hook -- that rank "forgets" to raise its p-slice flags in iteration
         // 3, so every bounded wait downstream of it expires: shows that the grid drains, the error surfaces on all
         // ranks and the caller survives (tests/test_gpu_rank_mock.py).  Never set it otherwise.
         static const char *drop = getenv("LAM_HIP_DEBUG_DIRECT_DROP");
-        if (drop && *drop && atoi(drop) == c->rank && k == 3) post.seq = ~0ull;
+        if (drop && *drop && atoi(drop) == me && k == 3) post.seq = ~0ull;
         hipLaunchKernelGGL((update_p_kernel<TV>), dim3(s.vec_blocks), dim3(kBlock), 0, s.stream, (const double *)nullptr, 0, s.sc, k,
                            rel_error, (const TV *)s.r, (const TV *)s.p + s.row0, pl, s.row0, s.nrows, (volatile int *)s.host_flags,
-                           MailWait{c->mail->rr, P, seq, c->direct_err}, post);
+                           MailWait{s.mail->rr, P, seq, c->direct_err}, post);
         LAUNCHED(c);
+        return 0;
+}
+
+int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        for (auto &s : c->sh) LAMCHK(enqueue_shard_direct<I>(c, s, k, rel_error, slot));
         return 0;
     });
 }
@@ -1225,7 +1272,7 @@ int do_cg_init(lam_hip_ctx *c)
 {
     c->cg_direct = false;
     c->epoch++;                    // mailbox tags = (epoch << 32) | iteration: never repeated across solves
-    c->waited_k = 0;
+    for (auto &sh_ : c->sh) sh_.waited_k = 0;
     if (c->direct_err) memset(c->direct_err, 0, 64);
     if (c->exchange2_wanted()) {
         // the state is initialised through RCCL (one-off); the iterations then run on the mailboxes
@@ -1243,7 +1290,8 @@ int do_cg_init(lam_hip_ctx *c)
             return fused_launch_resident<TV>(c, s0, s0.vec_blocks + 2) ? 1 : 0;
         }) == 1;
     }
-    if (c->fuse_active && !c->cg_direct) LAMCHK(ensure_mail(c, nullptr));
+    if (c->fuse_active)
+        for (auto &sh_ : c->sh) LAMCHK(ensure_mail(c, sh_, nullptr));
     if (c->exchange1_ok()) return do_cg_init_exchange1(c);
     c->cg_exchange1 = false;
     return dispatch(c, [&](auto impl) -> int {
@@ -1333,8 +1381,8 @@ int phase_xr(lam_hip_ctx *c, ShardBase &s, int k, double rel_error)
         for (auto &v : nb.n) v = 0;
         hipLaunchKernelGGL((update_fused_kernel<TV>), dim3(s.vec_blocks + 1), dim3(kBlock), 0, s.stream, red, nred, s.sc, k, rel_error,
                            (const TV *)s.p + s.row0, (const TV *)s.Ap, (TV *)s.x, (TV *)s.r, s.nrows, s.part_vec, s.vec_blocks, fr,
-                           MailWait{nullptr, 0, 0, nullptr}, MailWait{c->mail->rr, 1, seq, c->direct_err}, c->bcast, plist_p(c), s.row0,
-                           (volatile int *)s.host_flags, no_post(), (const Mail *)c->mail, nb);
+                           MailWait{nullptr, 0, 0, nullptr}, MailWait{s.mail->rr, 1, seq, c->direct_err}, s.bcast, plist_p(c), s.row0,
+                           (volatile int *)s.host_flags, no_post(), (const Mail *)s.mail, nb);
         LAUNCHED(c);
         return 0;
     }
@@ -1575,8 +1623,11 @@ void lam_hip_destroy(lam_hip_ctx *c)
     }
     close_direct(c);
     if (c->agree_buf) (void)hipFree(c->agree_buf);
-    if (c->mail) (void)hipFree(c->mail);
-    if (c->bcast) (void)hipFree(c->bcast);
+    for (auto &s : c->sh) {
+        if (hipSetDevice(s.dev) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (s.mail) { (void)hipFree(s.mail); s.mail = nullptr; }
+        if (s.bcast) { (void)hipFree(s.bcast); s.bcast = nullptr; }
+    }
     if (c->direct_err) (void)hipHostFree(c->direct_err);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     release_hub(c);

@@ -220,6 +220,13 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   iteration; consumers poll the tags (bounded).  Results are bit-identical to exchange 0.
  *                   Falls back to 0 when a mapping cannot be made (all ranks agree).  Re-run cg_init/solve
  *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts.
+ *                   ONE PROCESS WITH SEVERAL SHARDS (lam_hip_create): 0 (default) orders the shards' streams with
+ *                   events (HIP's own guarantees; ~0.25-0.6 ms of host time per iteration at 8 shards); 2 uses the
+ *                   same in-kernel flag exchange between the local shards -- no event, no stream wait, 2 launches per
+ *                   shard with "overlap" 0: 0.05 ms of host time per iteration at 8 shards, same bits as 0
+ *                   (profiles/r03_host_enqueue_cost.txt).  Needs every shard on a device of its own (kernels of one
+ *                   shard wait for kernels of the others); shards sharing a device get it only with
+ *                   LAM_HIP_DIRECT_SAME_DEVICE=1 and one hardware queue per stream (tests), else 0 is used.
  *   "symmetric"     single shard, fp64/fp32, N a multiple of 4096 (fp64) / 8192 (fp32): 1 = the matrix-vector
  *                   product reads only the upper triangle (A must equal its transpose, which CG requires
  *                   anyway; lam_hip_check_symmetry verifies it) -- about half the HBM traffic per iteration.

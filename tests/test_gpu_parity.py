@@ -703,3 +703,67 @@ def test_tuning_build_variants(lam):
         r = subprocess.run([sys.executable, probe, "4104", "8192", "--check", "--dtype", dtype, "--variants", variants],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count(" ok") == 2 * len(variants.split(",")), r.stdout + r.stderr[-2000:]
+
+
+_LOCAL_DIRECT = r"""
+import importlib, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
+P, n = int(sys.argv[1]), int(sys.argv[2])
+out = {}
+for label, exchange, overlap in (("events", 0, 1), ("direct", 2, 1), ("direct_nosplit", 2, 0)):
+    with lam.Solver(lam.F64, device_ids=[0] * P) as s:
+        s.generate_random_spd(n, 7, 200.0)
+        s.generate_random_rhs(8)
+        s.set_option("exchange", exchange)
+        s.set_option("overlap", overlap)
+        conv = s.solve(500, 1e-9)
+        res = dict(conv=bool(conv), iters=s.stats["num_iters"], eff=s.get_option("exchange_effective"),
+                   fallbacks=s.get_option("direct_fallbacks"), res=s.true_residual(), x=s.solution())
+        s.cg_init(); s.cg_iterate(8, 0.0)                 # (cg_init itself is event-ordered in every mode: one-off)
+        c0 = {k: s.get_option("hip_calls_" + k) for k in ("launch", "record", "wait")}
+        s.cg_iterate(40, 0.0)
+        c1 = {k: s.get_option("hip_calls_" + k) for k in ("launch", "record", "wait")}
+        res["per_iter"] = {k: (c1[k] - c0[k]) / 40 for k in c0}
+        out[label] = res
+ref = out["events"]["x"]
+print(json.dumps({k: dict(v, x=bool(np.array_equal(v["x"], ref)), xdiff=float(np.linalg.norm(v["x"] - ref) / np.linalg.norm(ref)))
+                  for k, v in out.items()}))
+"""
+
+
+@pytest.mark.parametrize("shards,n", [(2, 1024), (4, 4096), (8, 8192), (3, 3000)])
+def test_one_process_direct_exchange_matches_events(shards, n):
+    """One process, several shards, option exchange = 2: the shards' kernels hand their partial dot products and p
+    slices over through mailboxes and flags in each other's memory (the rank mode's direct exchange without the
+    mapping step), so an iteration needs NO event and NO stream wait from the host -- against the event-ordered
+    exchange: same bits, and the host-call count per iteration shows it.  All shards share GPU 0 here, which the
+    library only accepts on request (a waiting kernel must not sit in front of the kernel it waits for in a shared
+    hardware queue): LAM_HIP_DIRECT_SAME_DEVICE=1 with one hardware queue per stream; without the request the same
+    options fall back to the event exchange."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = _LOCAL_DIRECT % ROOT
+    env = dict(os.environ, LAM_HIP_DIRECT_SAME_DEVICE="1", GPU_MAX_HW_QUEUES=str(2 * shards + 4))
+    r = subprocess.run([sys.executable, "-c", code, str(shards), str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["events"]["eff"] == 0 and out["direct"]["eff"] == 2 and out["direct_nosplit"]["eff"] == 2, out
+    for v in out.values():
+        assert v["conv"] and abs(v["iters"] - out["events"]["iters"]) <= 1 and v["fallbacks"] == 0 and v["res"] < 2e-9 and v["xdiff"] < 1e-9, out
+    # one GEMV launch per shard, like the event exchange: the same bits (the own-slice panel of the split form adds a row's
+    # products in another order, so it agrees to rounding only)
+    assert out["direct_nosplit"]["x"] and out["direct_nosplit"]["iters"] == out["events"]["iters"], out
+    assert out["events"]["per_iter"]["wait"] >= 3 * shards * (shards - 1) - 1e-9
+    for k in ("direct", "direct_nosplit"):
+        assert out[k]["per_iter"]["wait"] == 0 and out[k]["per_iter"]["record"] <= 0.6, out[k]      # only the sampled GEMV timing pair
+    assert abs(out["direct_nosplit"]["per_iter"]["launch"] - 2 * shards) < 0.01                    # GEMV + fused update per shard
+    # not requested: shards sharing a device stay on the event exchange
+    env.pop("LAM_HIP_DIRECT_SAME_DEVICE")
+    r = subprocess.run([sys.executable, "-c", code, str(shards), str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [out[k]["eff"] for k in ("events", "direct", "direct_nosplit")] == [0, 0, 0] and out["direct_nosplit"]["x"]
