@@ -202,8 +202,9 @@ def main():
     ap.add_argument("--ramp", type=float, default=0.6, help="seconds of untimed GEMV launches before the warm-up steps of the headline "
                     "(device clock ramp, see clock_ramp); 0 = none")
     ap.add_argument("--config4-n", type=int, default=131072, help="matrix order of the configs[3] GEMV-only side run")
-    ap.add_argument("--cpu-sample-n", type=int, default=32768)
-    ap.add_argument("--cpu-sample-iters", type=int, default=10)
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="matrix order of the CPU baseline sample (0 = the workload's own N: "
+                    "no extrapolation; the reference driver needs 8*N^2 bytes of host memory)")
+    ap.add_argument("--cpu-sample-iters", type=int, default=20)
     args = ap.parse_args()
 
     # stdout carries ONE line, the JSON: native libraries print there too (RCCL writes a five-line version banner to
@@ -233,7 +234,7 @@ def main():
     # library initialises the GPU before main()).
     cb = None
     if solo and not args.no_cpu_baseline and not profiled:
-        cb = cpu_baseline(args.cpu_sample_n, args.cpu_sample_iters)
+        cb = cpu_baseline(args.cpu_sample_n or args.n, args.cpu_sample_iters)
     live_traffic = (None, None)
     if solo and not args.no_traffic and not profiled and not args.symmetric:
         live_traffic = measure_traffic(args.n)
@@ -508,9 +509,12 @@ def main():
         out["roofline"] = None     # the GEMV roofline does not describe this algorithm
     if solo and cb is not None:
         # same unit as `value`, scaled to the workload's N (bytes per iteration scale with N^2)
-        cb["value_at_sample_n"] = cb["value"]
-        cb["value"] = cb["value"] * (cb["sample_n"] / float(n)) ** 2
-        cb["sample"] += f"; value = measured it/s x ({cb['sample_n']}/{n})^2 to the workload's N"
+        if cb["sample_n"] != n:
+            cb["value_at_sample_n"] = cb["value"]
+            cb["value"] = cb["value"] * (cb["sample_n"] / float(n)) ** 2
+            cb["sample"] += f"; value = measured it/s x ({cb['sample_n']}/{n})^2 to the workload's N"
+        else:
+            cb["sample"] += "; measured at the workload's own N (bounded in iterations, not in size)"
         out["cpu_baseline"] = cb
     if rank == 0:
         sys.stdout.flush()
