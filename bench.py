@@ -115,11 +115,24 @@ def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=Fals
     if generate:
         s.generate_random_spd(n, seed, cond)
         s.generate_random_rhs(seed + 1)
-    if ramp_s > 0:
-        clock_ramp(s, ramp_s)
     s.set_option("symmetric", 1 if symmetric else 0)
     if symmetric and s.get_option("symmetric_effective") != 1:
         raise RuntimeError("option 'symmetric' is not available for this configuration")
+    cold = None
+    if ramp_s > 0:
+        # for the record: the same W + K steps measured WITHOUT the ramp, i.e. what round 2's bench measured (the device's
+        # first ~0.3 s of load after idling); reported next to the headline as "cold_start", never as `value`
+        s.cg_init()
+        if warmup > 0:
+            s.cg_iterate(warmup, 0.0)
+        barrier()
+        t0c = time.perf_counter()
+        st_c = s.cg_iterate(steps, 0.0)
+        barrier()
+        cold = {"value": steps / (time.perf_counter() - t0c), "gemv_ms": st_c["t_gemv"] * 1e3,
+                "what": "the same warm-up + timed steps right after the matrix generation, before the device ramp"}
+        clock_ramp(s, ramp_s)
+    run_config.cold = cold
     s.cg_init()
     if warmup > 0:
         s.cg_iterate(warmup, 0.0)
@@ -270,6 +283,7 @@ def main():
     default_exchange = s.get_option("exchange") if use_dist else None
     st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric, ramp_s=args.ramp)
     kernel_name = s.gemv_kernel_name()
+    cold_start = run_config.cold
 
     def max_over_ranks(dt_, st_):
         if rdzv is None:
@@ -484,6 +498,7 @@ def main():
         "gemv_gbps_per_gpu": achieved,
         "gemv_gbps_aggregate": achieved * n_gpus,
         "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res, "rccl_init_s": st.get("t_comm_init", 0.0),
+        **({"cold_start": cold_start} if cold_start else {}),
         "self_check": check, **({"error": "; ".join(failures), "value_unchecked": args.steps / dt} if failures else {}),
         **({"exchange_modes": exchange_modes} if exchange_modes else {}),
         "roofline": {"bound": "hbm", "kernel": kernel_name,
