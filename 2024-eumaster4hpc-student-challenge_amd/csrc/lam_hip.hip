@@ -1544,6 +1544,8 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
         c->sh[q].index = q;
         c->sh[q].dev = device_ids ? device_ids[q] : q % ndev;
     }
+    // default exchange of this context (only 0 and 2 mean something with several shards in one process)
+    if (const char *ex = getenv("LAM_HIP_EXCHANGE")) c->opt_exchange = atoi(ex) == 2 ? 2 : 0;
     int rc = create_common(c.get());
     if (rc != 0) { abandon(c.get()); return rc; }
     *out = c.release();

@@ -64,7 +64,10 @@ def test_getopt_driver_file_mode_against_golden_solution(golden, oracle, tmp_pat
     assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
 
 
-@pytest.mark.parametrize("exe,env", [(ONE_EXE, {}), (MULTI_EXE, {"LAM_NUM_SHARDS": "3"})])
+@pytest.mark.parametrize("exe,env", [(ONE_EXE, {}), (MULTI_EXE, {"LAM_NUM_SHARDS": "3"}),
+                                     # the one-process class on the in-kernel flag exchange (shards share GPU 0 here: on request)
+                                     (MULTI_EXE, {"LAM_NUM_SHARDS": "4", "LAM_HIP_EXCHANGE": "2", "LAM_HIP_DIRECT_SAME_DEVICE": "1",
+                                                  "GPU_MAX_HW_QUEUES": "12"})])
 def test_positional_drivers(golden, oracle, tmp_path, exe, env):
     """matrix rhs sol max_iters rel_error; prints the reference's 'Converged in K iterations' line."""
     for g in golden["file_mode"]:
