@@ -767,3 +767,29 @@ def test_one_process_direct_exchange_matches_events(shards, n):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert [out[k]["eff"] for k in ("events", "direct", "direct_nosplit")] == [0, 0, 0] and out["direct_nosplit"]["x"]
+
+
+@pytest.mark.parametrize("n,cycles,shards", [(2048, 40, 1), (10000, 6, 1), (4096, 8, 3)])
+def test_soak_in_kernel_handovers_stay_deterministic(lam, n, cycles, shards):
+    """Tens of thousands of in-launch hand-overs (reducer workgroup, fused-step broadcast, progress word): `cycles` solves
+    of 400 fixed iterations each on differently seeded ill-conditioned systems, the whole series repeated and run across
+    the launch-chain variants -- a hand-over that ever delivered a stale value would show up as a different bit in some x."""
+    import hashlib
+    ref = None
+    for rep, (fuse, timing) in enumerate(((1, 8), (1, 8), (0, 0), (1, 1))):
+        h = hashlib.sha256()
+        with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
+            for cyc in range(cycles):
+                s.generate_random_spd(n, 21 + cyc, 1e7)
+                s.generate_random_rhs(22 + cyc)
+                s.set_option("fuse_update", fuse)
+                s.set_option("gemv_timing", timing)
+                s.cg_init()
+                st = s.cg_iterate(400, 0.0)
+                x = s.solution()
+                assert st["num_iters"] == 401 and np.all(np.isfinite(x)) and 0 < st["rel_err"] < 1.0
+                h.update(x.tobytes())
+                h.update(np.float64(st["rel_err"]).tobytes())
+        if ref is None:
+            ref = h.hexdigest()
+        assert h.hexdigest() == ref, (rep, fuse, timing)
