@@ -142,6 +142,14 @@ struct lam_hip_ctx {
     int64_t opt_assume_cus = 0;    // testing: pretend the device has this many CUs when checking that a launch whose
                                    // workgroups wait for each other is fully resident (0 = ask the device)
     bool fuse_active = false;      // the current CG state uses update_fused_kernel (decided in cg_init: option + residency)
+    // whole-iteration persistent launch (lam_kernels.h, cg_persist_kernel): EXPERIMENT, option "persistent", off by default
+    int64_t opt_persistent = 0;
+    int64_t opt_persist_chunk = 32;             // iterations per launch
+    bool persist_active = false;                // the current CG state runs on it (decided in cg_init)
+    int persist_W = 0;                          // worker workgroups (+ 1 reducer)
+    BcastLine *persist_bc = nullptr;            // [kVecBlocksMax + persist lines] broadcast lines (device memory)
+    unsigned long long *persist_ticks = nullptr;        // device: [0] GEMV-phase ticks (100 MHz), [1] phases
+    unsigned long long *persist_ticks_host = nullptr;   // pinned mirror
     // runtime calls issued by the iteration loop (diagnostics: host cost of an iteration, tools/host_enqueue_cost.py)
     std::atomic<uint64_t> n_launch{0}, n_record{0}, n_wait{0}, n_setdev{0};
     uint64_t enqueue_ns = 0;       // host time spent issuing iterations (the waits for the device's progress excluded)
@@ -1268,6 +1276,85 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
     });
 }
 
+constexpr int kPersistLinesMax = 2048;      // >= the most worker workgroups a device can hold (8 x 256 CUs)
+
+// Can the current CG state run on the whole-iteration persistent launch, and with how many workers?  One shard, fp64 /
+// fp32, the fast GEMV path, not the symmetric product; the grid (W workers + the reducer) must be RESIDENT at once --
+// its workgroups wait for each other for the whole launch -- so W comes from the occupancy query (capped at 8 workgroups
+// of 256 threads per CU), rounded down to a multiple of the number of p tiles (every worker's pairs then share one
+// rotated tile order, which is what lets a group of pairs share a staged tile).
+int decide_persistent(lam_hip_ctx *c)
+{
+    c->persist_active = false;
+    if (c->persist_ticks_host) c->persist_ticks_host[0] = c->persist_ticks_host[1] = 0;
+    if (!c->opt_persistent || c->rank_mode || c->total_shards != 1 || c->dtype == LAM_HIP_BF16 || c->symv_active() || !c->opt_finalize) return 0;
+    ShardBase &s = c->sh[0];
+    LAMCHK(set_dev(c, s));
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TA = typename ImplTraits<I>::TA;
+        using TV = typename ImplTraits<I>::TV;
+        if constexpr (!std::is_same<TA, TV>::value) {
+            return 0;
+        } else {
+            if (!I::fast_ok(c) || s.nrows != c->n || (c->n % 2) != 0) return 0;
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_persist_kernel<TA, TV>, kBlock, 0) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.dev) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+            if (c->opt_assume_cus > 0) cus = (int)c->opt_assume_cus;
+            const int64_t npairs = (int64_t)(c->n / 2);
+            const int64_t ntiles = (int64_t)((c->n + 4095) / 4096);
+            int64_t W = std::min<int64_t>({(int64_t)std::min(per_cu, 8) * cus - 1, npairs, (int64_t)kPersistLinesMax});
+            W = W / ntiles * ntiles;
+            if (W < (int64_t)s.vec_blocks || W < 64) return 0;      // too few resident workgroups: two-launch form
+            if (c->persist_bc == nullptr) {
+                HIPCHK(c, hipMalloc((void **)&c->persist_bc, (size_t)(kVecBlocksMax + kPersistLinesMax) * sizeof(BcastLine)));
+                HIPCHK(c, hipMemset(c->persist_bc, 0, (size_t)(kVecBlocksMax + kPersistLinesMax) * sizeof(BcastLine)));
+                HIPCHK(c, hipMalloc((void **)&c->persist_ticks, 2 * sizeof(unsigned long long)));
+                HIPCHK(c, hipHostMalloc((void **)&c->persist_ticks_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+            }
+            HIPCHK(c, hipMemsetAsync(c->persist_ticks, 0, 2 * sizeof(unsigned long long), s.stream));
+            c->persist_W = (int)W;
+            c->persist_active = true;
+            return 0;
+        }
+    });
+}
+
+// `count` iterations starting at k_first in ONE launch
+int enqueue_persist_chunk(lam_hip_ctx *c, int k_first, int count, double rel_error)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TA = typename ImplTraits<I>::TA;
+        using TV = typename ImplTraits<I>::TV;
+        if constexpr (!std::is_same<TA, TV>::value) {
+            return fail(c, LAM_HIP_EINVAL, "persistent launch: not for this dtype");
+        } else {
+            ShardBase &s = c->sh[0];
+            LAMCHK(set_dev(c, s));
+            PersistArgs<TA, TV> a;
+            a.A = (const TA *)s.A; a.n = c->n;
+            a.pbuf[0] = (TV *)s.p; a.pbuf[1] = (TV *)s.tmp;
+            a.r = (TV *)s.r; a.x = (TV *)s.x; a.Ap = (TV *)s.Ap;
+            a.part_gemv = s.part_gemv; a.part_vec = s.part_vec;
+            a.sc = s.sc; a.k_first = k_first; a.k_count = count; a.rel_error = rel_error;
+            a.host_flags = (volatile int *)s.host_flags; a.host_err = c->direct_err;
+            a.bc_pap = c->persist_bc; a.bc_rr = c->persist_bc + kVecBlocksMax;
+            a.W = c->persist_W; a.vec_blocks = s.vec_blocks;
+            a.npairs = (uint32_t)(c->n / 2); a.ntiles = (uint32_t)((c->n + 4095) / 4096);
+            a.epoch_hi = (unsigned long long)c->epoch << 32;
+            a.ticks = c->persist_ticks;
+            hipLaunchKernelGGL((cg_persist_kernel<TA, TV>), dim3(c->persist_W + 1), dim3(kBlock), 0, s.stream, a);
+            LAUNCHED(c);
+            return 0;
+        }
+    });
+}
+
 int do_cg_init(lam_hip_ctx *c)
 {
     c->cg_direct = false;
@@ -1292,6 +1379,7 @@ int do_cg_init(lam_hip_ctx *c)
     }
     if (c->fuse_active)
         for (auto &sh_ : c->sh) LAMCHK(ensure_mail(c, sh_, nullptr));
+    LAMCHK(decide_persistent(c));
     if (c->exchange1_ok()) return do_cg_init_exchange1(c);
     c->cg_exchange1 = false;
     return dispatch(c, [&](auto impl) -> int {
@@ -1632,6 +1720,11 @@ void lam_hip_destroy(lam_hip_ctx *c)
     }
     if (c->direct_err) (void)hipHostFree(c->direct_err);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (!c->sh.empty() && hipSetDevice(c->sh[0].dev) == hipSuccess) {
+        if (c->persist_bc) (void)hipFree(c->persist_bc);
+        if (c->persist_ticks) (void)hipFree(c->persist_ticks);
+        if (c->persist_ticks_host) (void)hipHostFree(c->persist_ticks_host);
+    }
     release_hub(c);
     for (auto &s : c->sh) {
         free_shard(s);
@@ -2019,6 +2112,26 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     const bool threaded = !c->rank_mode && c->total_shards > 1 && c->opt_host_threads != 0 && !c->cg_direct && !c->cg_exchange1;
     if (stopped) {
         // nothing to enqueue
+    } else if (c->persist_active) {
+        // whole-iteration launches of `chunk` iterations; at most two of them are in the queue (the host waits for the
+        // last iteration of the launch before the previous one to report).  After a stop the queued launch returns at once.
+        const int chunk = (int)std::max<int64_t>(1, c->opt_persist_chunk);
+        int prev_last = 0, prev_prev_last = 0;
+        for (int done = 0; done < iters; ) {
+            const int cnt = std::min(chunk, iters - done);
+            if (prev_prev_last != 0) {
+                Progress pr;
+                LAMCHK(await_progress(c, s0, prev_prev_last, &pr));
+                if (pr.stop_at != 0 || *(volatile int *)c->direct_err != 0) break;
+            }
+            const double te = now_s();
+            LAMCHK(enqueue_persist_chunk(c, k_first + done, cnt, rel_error));
+            c->enqueue_ns += (uint64_t)((now_s() - te) * 1e9);
+            done += cnt;
+            prev_prev_last = prev_last;
+            prev_last = k_first + done - 1;
+            enq += cnt;
+        }
     } else if (threaded) {
         LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &gemv_ms, &gemv_samples));
         c->gather_pending = false;
@@ -2068,6 +2181,15 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         st->t_total = t1 - t0;
         st->t_iter = ran > 0 ? (t1 - t0) / ran : 0.0;
         st->t_gemv = gemv_samples > 0 ? gemv_ms * 1e-3 / gemv_samples : 0.0;
+        if (c->persist_active && c->persist_ticks != nullptr) {
+            // the persistent launch times its GEMV phases itself (constant-rate 100 MHz counter, reducer workgroup):
+            // from the previous hand-over to the moment the last partial of p.Ap has been summed
+            unsigned long long before[2] = {c->persist_ticks_host[0], c->persist_ticks_host[1]};
+            HIPCHK(c, hipMemcpyAsync(c->persist_ticks_host, c->persist_ticks, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s0.stream));
+            HIPCHK(c, hipStreamSynchronize(s0.stream));
+            const unsigned long long dt = c->persist_ticks_host[0] - before[0], dn = c->persist_ticks_host[1] - before[1];
+            st->t_gemv = dn > 0 ? (double)dt * 1e-8 / (double)dn : 0.0;
+        }
         st->t_comm_init = c->t_comm_init;
         st->gemv_bytes = (double)c->esz_a() * (double)s0.nrows * (double)c->n + (double)c->esz_v() * (double)(c->n + s0.nrows);
     }
@@ -2458,6 +2580,8 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
     else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
     else if (!strcmp(name, "fuse_update")) { c->opt_fuse = value; c->cg_ready = false; }
+    else if (!strcmp(name, "persistent")) { c->opt_persistent = value; c->cg_ready = false; }
+    else if (!strcmp(name, "persist_chunk")) c->opt_persist_chunk = value;
     else if (!strcmp(name, "symmetric")) { c->opt_symmetric = value; c->cg_ready = false; }   // other kernels, other partial arrays
     else if (!strcmp(name, "gemv_timing")) c->opt_gemv_timing = value < 0 ? 0 : value;
     else if (!strcmp(name, "verify_direct")) c->opt_verify_direct = value;
@@ -2489,6 +2613,10 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
     else if (!strcmp(name, "tuning_variants")) *value = Impl<double, double>::variant_available(1) ? 1 : 0;
     else if (!strcmp(name, "fuse_effective")) *value = c->fuse_active ? 1 : 0;
+    else if (!strcmp(name, "persistent")) *value = c->opt_persistent;
+    else if (!strcmp(name, "persistent_effective")) *value = c->persist_active ? 1 : 0;
+    else if (!strcmp(name, "persistent_workers")) *value = c->persist_active ? c->persist_W : 0;
+    else if (!strcmp(name, "persist_chunk")) *value = c->opt_persist_chunk;
     else if (!strcmp(name, "gemv_timing")) *value = c->opt_gemv_timing;
     else if (!strcmp(name, "verify_direct")) *value = c->opt_verify_direct;
     else if (!strcmp(name, "direct_fallbacks")) *value = c->direct_fallbacks;

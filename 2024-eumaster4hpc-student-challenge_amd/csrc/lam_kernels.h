@@ -400,6 +400,12 @@ template <typename TV> __device__ __forceinline__ TV widen(__hip_bfloat16 v)
     return (TV)__uint_as_float(((unsigned)*reinterpret_cast<const unsigned short *>(&v)) << 16);
 }
 
+// The GEMV's multiply-add, fused EXPLICITLY: left to -ffp-contract the fp32 kernels came out as packed multiplies
+// followed by separate adds in some instantiations (v_pk_mul_f32 + v_pk_add_f32: twice the VALU work, and a rounding that
+// depended on how the loop happened to be vectorised) and as v_pk_fma_f32 in others.  fp64 always compiled to v_fma_f64.
+__device__ __forceinline__ double fma_tv(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_tv(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // ---------------------------------------------------------------------------------------------
 // GEMV  y_loc = A_loc * p        (A_loc: nrows x n row-major, p: n, y_loc: nrows)
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +510,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
+                    for (int i = 0; i < VEC; i++) acc[r] = fma_tv((TV)MV::get(av[r], i), pv[i], acc[r]);
             }
         } else {
             // Ragged last tile of a segment (N not a multiple of TILE: 18 % of the columns at N=10000): the SAME
@@ -531,7 +537,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
+                    for (int i = 0; i < VEC; i++) acc[r] = fma_tv((TV)MV::get(av[r], i), pv[i], acc[r]);
             }
         }
         tt = (tt + 1 == ntiles) ? 0 : tt + 1;
@@ -642,7 +648,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
+                    for (int i = 0; i < VEC; i++) acc[r] = fma_tv((TV)MV::get(av[r], i), pv[i], acc[r]);
             }
         } else {
             // ragged last tile of a segment: the same streaming body over ceil(cols / super-step) super-steps; lanes past
@@ -666,7 +672,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
                 for (int r = 0; r < R; r++)
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) acc[r] += (TV)MV::get(av[r], i) * pv[i];
+                    for (int i = 0; i < VEC; i++) acc[r] = fma_tv((TV)MV::get(av[r], i), pv[i], acc[r]);
             }
         }
         tt = (tt + 1 == ntiles) ? 0 : tt + 1;
@@ -700,6 +706,60 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
             for (int r = 1; r < R; r++) t += s_dot[r];
         }
         publish_partial(t, a.partial, a.fin);
+    }
+}
+
+// One p tile's worth of the cooperative-row stream as a function: R rows, columns [c0, c0 + cols) of each, accumulated
+// into acc[R] -- statement for statement the tile body of gemv_coop_kernel (which keeps its own inline copy: moving it
+// behind this call changed the production kernels' register allocation), so that cg_persist_kernel adds a row's
+// products in exactly the same order.  rowp[r] points at the row's element `woff` (this lane's column inside a
+// super-step); s_p holds p[c0 ...] with zeros behind `cols` up to the next whole super-step.
+template <typename TA, typename TV, int R, int TILE, bool NT, int UNROLL, int WAVES>
+__device__ __forceinline__ void coop_stream_tile(const TA *const (&rowp)[R], uint64_t c0, uint32_t cols, const TV *s_p, uint32_t woff, TV (&acc)[R])
+{
+    using MV = MatVec<TA>;
+    using avec_t = typename MV::vec_t;
+    constexpr int VEC = MV::N;
+    constexpr int STEP = 64 * VEC;
+    constexpr int WSTEPS = TILE / (STEP * WAVES);
+    if (cols == TILE) {
+#pragma unroll UNROLL
+        for (int s = 0; s < WSTEPS; s++) {
+            avec_t av[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] + c0 + (uint64_t)s * (STEP * WAVES));
+                av[r] = NT ? __builtin_nontemporal_load(src) : *src;
+            }
+            TV pv[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; i++) pv[i] = s_p[s * (STEP * WAVES) + woff + i];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int i = 0; i < VEC; i++) acc[r] = fma_tv((TV)MV::get(av[r], i), pv[i], acc[r]);
+        }
+    } else {
+        const int nsteps = (int)((cols + STEP * WAVES - 1) / (STEP * WAVES));
+        const uint32_t last = cols - VEC;
+#pragma unroll UNROLL
+        for (int s = 0; s < nsteps; s++) {
+            const uint32_t col = (uint32_t)s * (STEP * WAVES) + woff;
+            const uint32_t colc = col < last ? col : last;
+            avec_t av[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const avec_t *src = reinterpret_cast<const avec_t *>(rowp[r] - woff + c0 + colc);
+                av[r] = NT ? __builtin_nontemporal_load(src) : *src;
+            }
+            TV pv[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; i++) pv[i] = s_p[col + i];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int i = 0; i < VEC; i++) acc[r] = fma_tv((TV)MV::get(av[r], i), pv[i], acc[r]);
+        }
     }
 }
 
@@ -1424,6 +1484,324 @@ update_p_full_kernel(const double *__restrict__ red, int nred, CgScalars *sc, in
     const TV beta = (TV)beta_d;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
         p_full[i] = r_full[i] + beta * p_full[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-iteration persistent launch (option "persistent"; one shard, fp64 / fp32, N a multiple of the vector width).
+// EXPERIMENT, off by default; DESIGN.md section 6 has the measurement.
+//
+// One launch runs `k_count` CG iterations.  The grid is W worker workgroups + ONE reducer workgroup, all resident at
+// once (the host checks the occupancy before it uses this kernel).  Per iteration:
+//   * GEMV.  Worker w owns the row pairs q = w, w + W, w + 2W, ... (W is a multiple of the number of p tiles, so all
+//     of them start their rotated tile order at the same tile) and handles them in groups of kPersistGroup: one p tile
+//     is staged in LDS ONCE per group and every pair of the group streams its two rows against it with the tile body
+//     of gemv_coop_kernel (coop_stream_tile) -- a row's products are added in exactly the order of the two-launch form.
+//     Ap goes to memory with agent-scope (write-through) stores; the pair's partial of p.Ap goes to part_gemv[q], the
+//     same slot and value the two-launch form writes.
+//   * p is never "updated" in a phase of its own: from the second iteration of a launch on, a tile of
+//     p_k = r_k + beta_k p_{k-1} is formed WHILE IT IS STAGED, from r and the last explicitly stored p (two 16-byte
+//     sc1 loads and one FMA per element instead of one load; a quarter of the staging the two-launch GEMV does, because
+//     of the groups).  That removes the third grid-wide dependency of an iteration: two hand-overs remain.
+//   * hand-over 1: the reducer workgroup sums the partials in the order of block_sum_array (bit-identical p.Ap) while
+//     the GEMV is still running, and broadcasts the total to the first `vec_blocks` workers, each on a line of its own.
+//   * vector step on those workers, with the element -> (workgroup, thread) mapping of update_xr_kernel: p_k[i] is
+//     formed once more (and stored: it is the "last explicit p" of the next iteration, in the other of two buffers),
+//     x += alpha p, r -= alpha Ap, partials of r.r to part_vec[cb].
+//   * hand-over 2: the reducer sums them (bit-identical r.r) and broadcasts to ALL workers: beta, the stop test (every
+//     workgroup takes the same decision from the same bits), and the next GEMV starts -- no kernel boundary, no launch
+//     ramp.  Worker 0 keeps CgScalars and the host's progress word up to date.
+//   * on exit the explicit p of the two-launch form is materialised in pbuf[0], so either form can continue the solve.
+// Everything handed over inside the launch is written with sc1 stores that the writing wave drains (s_waitcnt vmcnt(0))
+// before the workgroup's flag goes out, and read with sc1 loads (MI355X_MICROARCH.md, "Valid forms"); every wait is
+// bounded (SpinGuard) and reports through host_err.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPersistGroup = 4;
+
+template <typename TA, typename TV>
+struct PersistArgs {
+    const TA *A;
+    uint64_t n;
+    TV *pbuf[2];                  // [0] the shard's p (explicit on entry and on exit), [1] a scratch vector
+    TV *r, *x, *Ap;
+    double *part_gemv;            // [npairs], armed with the sentinel
+    double *part_vec;             // [vec_blocks], armed
+    CgScalars *sc;
+    int k_first, k_count;
+    double rel_error;
+    volatile int *host_flags;
+    int *host_err;
+    BcastLine *bc_pap;            // [vec_blocks]
+    BcastLine *bc_rr;             // [W]
+    int W, vec_blocks;
+    uint32_t npairs, ntiles;
+    unsigned long long epoch_hi;  // solve epoch << 32: tags never repeat
+    unsigned long long *ticks;    // [0] += constant-rate ticks (100 MHz) spent in GEMV phases, [1] += phases
+};
+
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p);
+template <> __device__ __forceinline__ double ld_agent<double>(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <> __device__ __forceinline__ float ld_agent<float>(const float *p)
+{
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte sc1 load (L1-bypassing, what a hand-over inside a launch needs) as issued / waited-for pair: the compiler does
+// not know the load is asynchronous, so every register it fills is tied to the wait below before anything reads it
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t ld16_sc1_issue(const void *p)
+{
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld16_wait(u32x4_t &a, u32x4_t &b, u32x4_t &c, u32x4_t &d, u32x4_t &e, u32x4_t &f, u32x4_t &g, u32x4_t &h)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "memory");
+}
+
+// bcast_wait for the persistent launch.  There a worker waits for a WHOLE GEMV phase of the slowest worker (tens of
+// microseconds to milliseconds), and a thousand workgroups wait at once: the abort word in pinned host memory (a PCIe read)
+// and the clock are looked at once every 8192 failed polls (the first version read it every 256 polls and once per iteration
+// in every thread: ~650 us per iteration at every N, all of it PCIe reads).  Polls back off from s_sleep 1 to s_sleep 8 after 512 of them.
+__device__ __forceinline__ double persist_wait(const BcastLine *line, unsigned long long seq, int *host_err, double *s_red)
+{
+    const MailSlot *slot = &line->s;
+    double v = 0.0;
+    if (threadIdx.x == 0) {
+        unsigned polls = 0;
+        unsigned long long t0 = 0, seen;
+        while ((seen = __hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != seq) {
+            if ((++polls & 8191u) == 0) {
+                const unsigned long long now = (unsigned long long)clock64();
+                if (t0 == 0) t0 = now | 1ull;
+                if (*(volatile int *)host_err != 0) break;
+                if (now - t0 > kSpinTimeoutCycles) {
+                    host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
+                    host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
+                    *(volatile int *)host_err = 4;
+                    break;
+                }
+            }
+            if (polls < 512u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
+        }
+        v = __longlong_as_double((long long)__hip_atomic_load(&slot->value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return block_sum(v, s_red);
+}
+
+template <typename TA, typename TV>
+__global__ void __launch_bounds__(kBlock, 4)      // 4 waves per SIMD = 4 workgroups per CU (what the LDS tile allows in fp64): <= 128 VGPRs
+cg_persist_kernel(PersistArgs<TA, TV> a)
+{
+    static_assert(std::is_same<TA, TV>::value, "persistent launch: matrix and vectors of one type");
+    using MV = MatVec<TA>;
+    constexpr int VEC = MV::N, R = 2, TILE = 4096, WAVES = 4, UNROLL = 4, G = kPersistGroup;
+    constexpr int STEP = 64 * VEC;
+    constexpr int PV = 16 / sizeof(TV);
+    typedef TV pvec_t __attribute__((ext_vector_type(PV)));
+
+    __shared__ __attribute__((aligned(16))) TV s_p[TILE];
+    __shared__ TV s_part[G][R][WAVES];
+    __shared__ double s_dot[G * R];
+    __shared__ double s_red[kWaves];
+
+    if (a.sc->stop) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = (int)blockIdx.x;
+    const uint64_t n = a.n;
+    const double bb = a.sc->bb;
+
+    if (w == a.W) {
+        // ---- the reducer workgroup: both hand-overs of every iteration
+        unsigned long long t_prev = wall_clock64();
+        for (int it = 0; it < a.k_count; it++) {
+            const unsigned long long seq = a.epoch_hi | (unsigned)(a.k_first + it);
+            const double pAp = reduce_partials_sum(a.part_gemv, (int)a.npairs, s_red, a.host_err);
+            const unsigned long long t_gemv_end = wall_clock64();
+            bcast_post(a.bc_pap, a.vec_blocks, pAp, seq);
+            const double rr_new = reduce_partials_sum(a.part_vec, a.vec_blocks, s_red, a.host_err);
+            bcast_post(a.bc_rr, a.W, rr_new, seq);
+            if (tid == 0) { a.ticks[0] += t_gemv_end - t_prev; a.ticks[1] += 1; }
+            t_prev = wall_clock64();
+            if (sqrt(rr_new / bb) < a.rel_error) return;
+            if (!(rr_new == rr_new)) return;              // a bounded wait expired somewhere (NaN total): the launch drains
+        }
+        return;
+    }
+
+    const uint32_t woff = (uint32_t)wave * STEP + (uint32_t)lane * VEC;
+    double rr_old = a.sc->rr[(a.k_first + 1) & 1];
+    TV beta = (TV)0;
+    int cur = 0;                                  // pbuf[cur]: the last explicitly stored p
+    for (int it = 0; it < a.k_count; it++) {
+        const int k = a.k_first + it;
+        const unsigned long long seq = a.epoch_hi | (unsigned)k;
+        const bool direct = it == 0;              // p_{k-1} is explicit in pbuf[cur]; else p_{k-1} = r + beta pbuf[cur]
+        const TV *pold = a.pbuf[cur];
+        TV *pdst = a.pbuf[cur ^ 1];
+
+        // ---- GEMV over the pairs this worker owns, kPersistGroup at a time
+        for (uint32_t q0 = (uint32_t)w; q0 < a.npairs; q0 += (uint32_t)(G * a.W)) {
+            TV acc[G][R];
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[g][r] = (TV)0;
+            const TA *const lane0 = a.A + woff;            // row pointers are rebuilt per (tile, pair): 16 registers less
+            uint32_t tt = (uint32_t)w % a.ntiles;          // == q % ntiles for every pair of this worker (W % ntiles == 0)
+            for (uint32_t t = 0; t < a.ntiles; t++) {
+                const uint64_t c0 = (uint64_t)tt * TILE;
+                const uint32_t cols = (uint32_t)((n - c0 < (uint64_t)TILE) ? (n - c0) : (uint64_t)TILE);
+                const uint32_t nv = cols / PV;
+                __syncthreads();                           // the previous tile is fully consumed
+                if (direct) {
+                    const pvec_t *src = reinterpret_cast<const pvec_t *>(pold + c0);
+                    pvec_t *dst = reinterpret_cast<pvec_t *>(s_p);
+                    for (uint32_t i = tid; i < nv; i += kBlock) dst[i] = src[i];
+                } else {
+                    // p_k = r_k + beta p_{k-1}, formed while it is staged (same expression as update_p_kernel)
+                    const char *rsrc = reinterpret_cast<const char *>(a.r + c0), *psrc = reinterpret_cast<const char *>(pold + c0);
+                    for (uint32_t base = 0; base < nv; base += 4 * kBlock) {
+                        u32x4_t rv[4], pv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            uint32_t i = base + u * kBlock + tid;
+                            if (i >= nv) i = nv - 1;        // clamped: in bounds, result not stored
+                            rv[u] = ld16_sc1_issue(rsrc + (size_t)i * 16);
+                            pv[u] = ld16_sc1_issue(psrc + (size_t)i * 16);
+                        }
+                        ld16_wait(rv[0], rv[1], rv[2], rv[3], pv[0], pv[1], pv[2], pv[3]);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t i = base + u * kBlock + tid;
+                            if (i < nv) {
+                                const pvec_t rr_ = __builtin_bit_cast(pvec_t, rv[u]), pp_ = __builtin_bit_cast(pvec_t, pv[u]);
+                                pvec_t o;
+#pragma unroll
+                                for (int e = 0; e < PV; e++) o[e] = rr_[e] + beta * pp_[e];
+                                reinterpret_cast<pvec_t *>(s_p)[i] = o;
+                            }
+                        }
+                    }
+                }
+                for (uint32_t i = cols + tid; i < (uint32_t)TILE && i < (cols + STEP * WAVES - 1) / (STEP * WAVES) * (STEP * WAVES); i += kBlock)
+                    s_p[i] = (TV)0;
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const uint64_t q = (uint64_t)q0 + (uint64_t)g * (uint64_t)a.W;
+                    if (q < a.npairs) {
+                        const TA *rowp[R];
+#pragma unroll
+                        for (int r = 0; r < R; r++) rowp[r] = lane0 + (q * R + r) * n;
+                        coop_stream_tile<TA, TV, R, TILE, true, UNROLL, WAVES>(rowp, c0, cols, s_p, woff, acc[g]);
+                    }
+                }
+                tt = (tt + 1 == a.ntiles) ? 0 : tt + 1;
+            }
+            // epilogue of the group: row sums across the waves in the fixed order of gemv_coop_kernel
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const TV sacc = wave_sum(acc[g][r]);
+                    if (lane == 0) s_part[g][r][wave] = sacc;
+                }
+            __syncthreads();
+            if (tid < G * R) {
+                const int g = tid / R, r = tid % R;
+                const uint64_t q = (uint64_t)q0 + (uint64_t)g * (uint64_t)a.W;
+                double d = 0.0;
+                if (q < a.npairs) {
+                    const uint64_t row = q * R + r;
+                    TV sum = s_part[g][r][0];
+#pragma unroll
+                    for (int wv = 1; wv < WAVES; wv++) sum += s_part[g][r][wv];
+                    st_agent(a.Ap + row, sum);
+                    const TV pk = direct ? pold[row] : (TV)(ld_agent(a.r + row) + beta * ld_agent(pold + row));
+                    d = (double)sum * (double)pk;
+                }
+                s_dot[tid] = d;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the Ap stores have left before the partial says so
+            __syncthreads();
+            if (tid < G) {
+                const uint64_t q = (uint64_t)q0 + (uint64_t)tid * (uint64_t)a.W;
+                if (q < a.npairs) {
+                    double t = s_dot[tid * R];
+#pragma unroll
+                    for (int r = 1; r < R; r++) t += s_dot[tid * R + r];
+                    __hip_atomic_store(a.part_gemv + q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+
+        // ---- vector step on the first vec_blocks workers (update_xr_kernel's mapping and arithmetic)
+        if (w < a.vec_blocks) {
+            // what does not depend on p.Ap is fetched BEFORE waiting for it (r, p and x of the thread's first element --
+            // its only one up to N = 65536): the loads' latency then hides under the end of the GEMV phase
+            const uint64_t stride = (uint64_t)a.vec_blocks * kBlock;
+            const uint64_t i_first = (uint64_t)w * kBlock + tid;
+            TV r_first = (TV)0, p_first = (TV)0, x_first = (TV)0;
+            if (i_first < n) {
+                r_first = ld_agent(a.r + i_first);
+                p_first = direct ? pold[i_first] : ld_agent(pold + i_first);
+                x_first = a.x[i_first];
+            }
+            const double pAp = persist_wait(a.bc_pap + w, seq, a.host_err, s_red);
+            const double alpha_d = rr_old / pAp;
+            const TV alpha = (TV)alpha_d;
+            double accv = 0.0;
+            for (uint64_t i = i_first; i < n; i += stride) {
+                const bool first = i == i_first;
+                const TV ri0 = first ? r_first : ld_agent(a.r + i);
+                TV pi;
+                if (direct) pi = first ? p_first : pold[i];
+                else {
+                    pi = ri0 + beta * (first ? p_first : ld_agent(pold + i));
+                    st_agent(pdst + i, pi);
+                }
+                a.x[i] = alpha * pi + (first ? x_first : a.x[i]);
+                const TV ri = -alpha * ld_agent(a.Ap + i) + ri0;
+                st_agent(a.r + i, ri);
+                accv += (double)ri * (double)ri;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // r and p stores have left before the partial says so
+            const double t = block_sum(accv, s_red);
+            if (tid == 0) {
+                if (w == 0) { a.sc->pAp = pAp; a.sc->alpha = alpha_d; }
+                __hip_atomic_store(a.part_vec + w, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!direct) cur ^= 1;                         // pdst now holds the explicit p_{k-1}
+
+        // ---- hand-over 2: r.r of this iteration, for everybody
+        const double rr_new = persist_wait(a.bc_rr + w, seq, a.host_err, s_red);
+        const double beta_d = rr_new / rr_old;
+        const bool stop = sqrt(rr_new / bb) < a.rel_error;
+        if (w == 0 && tid == 0) {
+            a.sc->rr[k & 1] = rr_new;
+            a.sc->beta = beta_d;
+            a.sc->iters = k;
+            post_progress(a.host_flags, k, stop);
+            if (stop) a.sc->stop = 1;
+        }
+        if (stop) return;                              // like the two-launch form: p is not updated by the stopping iteration
+        if (!(rr_new == rr_new)) return;               // a bounded wait expired somewhere (NaN total): the launch drains
+        beta = (TV)beta_d;
+        rr_old = rr_new;
+    }
+    // ---- leave the explicit p of the two-launch form behind: p_k = r_k + beta_k p_{k-1}
+    if (w < a.vec_blocks) {
+        const TV *pold = a.pbuf[cur];
+        const uint64_t stride = (uint64_t)a.vec_blocks * kBlock;
+        for (uint64_t i = (uint64_t)w * kBlock + tid; i < n; i += stride)
+            a.pbuf[0][i] = ld_agent(a.r + i) + beta * ld_agent(pold + i);
+    }
 }
 
 // standalone BLAS-1 pieces (lam_hip_dot / lam_hip_axpby and the residual check)

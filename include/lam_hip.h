@@ -241,6 +241,12 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   The fused launch's workgroups wait for each other, so it is used only when cg_init finds that
  *                   the whole grid can be resident at once (occupancy x CU count; "fuse_effective" tells,
  *                   "assume_cus" overrides the CU count for tests); otherwise the two-kernel form runs.
+ *   "persistent"    one shard, fp64/fp32, even N a multiple of the 16-byte vector width: 1 = EXPERIMENT, whole CG
+ *                   iterations inside one launch ("persist_chunk", default 32, iterations per launch): resident GEMV
+ *                   workers + one reducer workgroup, two in-launch hand-overs per iteration, same bits as the
+ *                   two-launch chain; measured 0.7-2 % SLOWER (profiles/r03_persistent_vs_two_launch.txt), so 0 is the
+ *                   default.  "persistent_effective" / "persistent_workers" tell what cg_init decided (the grid must
+ *                   be resident at once: occupancy x CU count).
  *   "gemv_timing"   T (default 8): a HIP-event pair brackets the GEMV of every T-th iteration (lam_hip_stats.t_gemv is
  *                   their average); 1 = every iteration (costs ~8 us per iteration: each record is a marker packet
  *                   between the kernels), 0 = never (t_gemv = 0).  The host follows the iteration through a progress

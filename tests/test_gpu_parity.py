@@ -793,3 +793,30 @@ def test_soak_in_kernel_handovers_stay_deterministic(lam, n, cycles, shards):
         if ref is None:
             ref = h.hexdigest()
         assert h.hexdigest() == ref, (rep, fuse, timing)
+
+
+@pytest.mark.parametrize("dtype_name,n", [("F64", 4096), ("F64", 10000), ("F64", 1000), ("F32", 8192), ("F64", 12290)])
+def test_persistent_launch_is_bit_identical_to_the_two_launch_chain(lam, dtype_name, n):
+    """Option "persistent" (experiment): whole iterations inside ONE launch -- persistent GEMV workers, p formed while
+    its tile is staged, two in-launch hand-overs per iteration -- must be the same arithmetic as the two-launch chain:
+    identical iteration counts, residuals and solution bits, whatever the number of iterations per launch (each launch
+    ends by materialising the explicit p the two-launch form keeps) and however the solve is cut into calls."""
+    dt = getattr(lam, dtype_name)
+    tol = 1e-9 if dtype_name == "F64" else 1e-5
+    res = []
+    for persistent, chunk in ((0, 32), (1, 32), (1, 1), (1, 5)):
+        with lam.Solver(dt) as s:
+            s.generate_random_spd(n, 5, 300.0)
+            s.generate_random_rhs(6)
+            s.set_option("persistent", persistent)
+            s.set_option("persist_chunk", chunk)
+            s.solve(400, tol)
+            assert s.get_option("persistent_effective") == persistent
+            assert s.stats["converged"]
+            out = (s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes(), s.true_residual())
+            s.cg_init()
+            for _ in range(3):
+                st = s.cg_iterate(7, 0.0)
+            assert st["t_gemv"] > 0
+            res.append(out + (s.solution().tobytes(), st["rel_err"]))
+    assert res[0] == res[1] == res[2] == res[3]
