@@ -319,7 +319,7 @@ struct Impl {
     // profiles/r01_gemv_variant_sweep.txt), 0 (4 rows per wave: bf16 production), 21 / 20 (MFMA-fed bf16, p exact /
     // p rounded: BASELINE configs[3]'s comparison).  The other 19 are tuning scaffolding and exist only in the
     // library built with -DLAM_TUNING_VARIANTS (`make tuning` -> liblam_hip_tuning.so, used by tools/gemv_probe.py).
-    static constexpr int kNumVariants = 23;
+    static constexpr int kNumVariants = 25;      // 23, 24: tuning probes gemv_coop_group_kernel (2 / 4 row pairs per workgroup)
     static bool variant_available(int v)
     {
 #ifdef LAM_TUNING_VARIANTS
@@ -332,7 +332,8 @@ struct Impl {
     static int variant_rows_per_block(int v)
     {
         static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 2, 2, 2, 4, 3,
-                                                  /* 19-22: MFMA bf16 experiment (bf16 storage only) */ 8, 8, 16, 4};
+                                                  /* 19-22: MFMA bf16 experiment (bf16 storage only) */ 8, 8, 16, 4,
+                                                  /* 23, 24: grouped cooperative rows (tuning probe) */ 4, 8};
         return rows[v];
     }
 
@@ -368,6 +369,8 @@ struct Impl {
         else if (v <= 18)
             snprintf(buf, sizeof buf, "gemv_coop_kernel<%s,%s,R=%d,TILE=%d,NT=%s,UNROLL=%d,WAVES=%d>", ta, tv, coops[v - 9].r,
                      coops[v - 9].tile, nt, coops[v - 9].unroll, coops[v - 9].waves);
+        else if (v >= 23)
+            snprintf(buf, sizeof buf, "gemv_coop_group_kernel<%s,%s,GROUP=%d>", ta, tv, v == 23 ? 2 : 4);
         else {
             static const int mf[4][2] = {{2, 3}, {2, 1}, {4, 3}, {1, 3}};      // {R, SPLIT} of variants 19..22
             snprintf(buf, sizeof buf, "gemv_mfma_bf16_kernel<R=%d,TILE=4096,NT=true,SPLIT=%d>", mf[v - 19][0], mf[v - 19][1]);
@@ -487,6 +490,8 @@ struct Impl {
             case 16: launch_coop<2, 8192, 4, 8>(c, grid, s.stream, a); break;
             case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
             case 18: launch_coop<3>(c, grid, s.stream, a); break;
+            case 23: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 2>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
+            case 24: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
 #endif
             case 19: case 20: case 21: case 22:
                 if constexpr (sizeof(TA) == 2) {

@@ -763,6 +763,94 @@ __device__ __forceinline__ void coop_stream_tile(const TA *const (&rowp)[R], uin
     }
 }
 
+#ifdef LAM_TUNING_VARIANTS
+// Tuning probe (not in the product library): the cooperative-row GEMV with GROUP consecutive row pairs per workgroup that
+// share every staged p tile -- does halving / quartering the number of workgroups (launches, epilogues, staged tiles) lift
+// the short-row sizes?  Same per-row arithmetic; the rotated tile order starts at blockIdx (not pair index) % tiles, so the
+// bits differ from the production kernel's.
+template <typename TA, typename TV, int GROUP>
+__global__ void __launch_bounds__(kBlock)
+gemv_coop_group_kernel(GemvArgs<TA, TV> a)
+{
+    using MV = MatVec<TA>;
+    constexpr int VEC = MV::N, R = 2, TILE = 4096, WAVES = 4, UNROLL = 4;
+    constexpr int STEP = 64 * VEC;
+    __shared__ __attribute__((aligned(16))) TV s_p[TILE];
+    __shared__ TV s_part[GROUP][R][WAVES];
+    __shared__ double s_dot[GROUP * R];
+    __shared__ double s_red[kWaves];
+    if (a.sc != nullptr && a.sc->stop) return;
+    if (is_reducer_block(a.fin)) { reduce_partials(a.partial, (int)gridDim.x - 1, a.fin, s_red); return; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t n = a.n;
+    const uint64_t row_first = (uint64_t)blockIdx.x * R * GROUP;
+    const uint32_t woff = (uint32_t)wave * STEP + (uint32_t)lane * VEC;
+    TV acc[GROUP][R];
+#pragma unroll
+    for (int g = 0; g < GROUP; g++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[g][r] = (TV)0;
+    const uint32_t ntiles = (uint32_t)((n + TILE - 1) / TILE);
+    uint32_t tt = blockIdx.x % ntiles;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint64_t c0 = (uint64_t)tt * TILE;
+        const uint32_t cols = (uint32_t)((n - c0 < (uint64_t)TILE) ? (n - c0) : (uint64_t)TILE);
+        __syncthreads();
+        {
+            constexpr int PV = 16 / sizeof(TV);
+            typedef TV pvec_t __attribute__((ext_vector_type(PV)));
+            const pvec_t *src = reinterpret_cast<const pvec_t *>(a.p + c0);
+            pvec_t *dst = reinterpret_cast<pvec_t *>(s_p);
+            const uint32_t nv = cols / PV;
+            for (uint32_t i = tid; i < nv; i += kBlock) dst[i] = src[i];
+            for (uint32_t i = nv * PV + tid; i < cols; i += kBlock) s_p[i] = a.p[c0 + i];
+            for (uint32_t i = cols + tid; i < (uint32_t)TILE && i < (cols + STEP * WAVES - 1) / (STEP * WAVES) * (STEP * WAVES); i += kBlock) s_p[i] = (TV)0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < GROUP; g++) {
+            const TA *rowp[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint64_t row = row_first + (uint64_t)g * R + r;
+                if (row >= a.nrows) row = a.nrows - 1;
+                rowp[r] = a.A + row * n + woff;
+            }
+            coop_stream_tile<TA, TV, R, TILE, true, UNROLL, WAVES>(rowp, c0, cols, s_p, woff, acc[g]);
+        }
+        tt = (tt + 1 == ntiles) ? 0 : tt + 1;
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; g++)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const TV sacc = wave_sum(acc[g][r]);
+            if (lane == 0) s_part[g][r][wave] = sacc;
+        }
+    __syncthreads();
+    if (tid < GROUP * R) {
+        const int g = tid / R, r = tid % R;
+        const uint64_t row = row_first + (uint64_t)g * R + r;
+        double d = 0.0;
+        if (row < a.nrows) {
+            TV sum = s_part[g][r][0];
+#pragma unroll
+            for (int wv = 1; wv < WAVES; wv++) sum += s_part[g][r][wv];
+            a.y[row] = sum;
+            d = (double)sum * (double)a.p[a.row0 + row];
+        }
+        s_dot[tid] = d;
+    }
+    if (a.partial != nullptr) {
+        __syncthreads();
+        double t = 0.0;
+        if (tid == 0)
+            for (int i = 0; i < GROUP * R; i++) t += s_dot[i];
+        publish_partial(t, a.partial, a.fin);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // MFMA experiment for the bf16-storage GEMV (BASELINE configs[3]): can the matrix cores take the
 // widening + FMA work off the VALU?  A wave loads 1 KiB = 512 contiguous bf16 of ONE matrix row

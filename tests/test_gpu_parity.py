@@ -698,7 +698,7 @@ def test_tuning_build_variants(lam):
         for v in (-1, 0, 10):
             s.set_option("gemv_variant", v)
     probe = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "gemv_probe.py")
-    for dtype, variants in (("f64", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18"), ("f32", "0,8,9,10,12,15,18"),
+    for dtype, variants in (("f64", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,23,24"), ("f32", "0,8,9,10,12,15,18,23"),
                             ("bf16", "0,1,10,19,20,21,22")):
         r = subprocess.run([sys.executable, probe, "4104", "8192", "--check", "--dtype", dtype, "--variants", variants],
                            capture_output=True, text=True, timeout=600)
