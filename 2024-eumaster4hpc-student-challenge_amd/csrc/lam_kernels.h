@@ -1065,15 +1065,15 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                 if (!masked) {
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        racc[r] += a[k][i] * pc[i];
-                        cacc[i] += a[k][i] * pr;
+                        racc[r] = fma_tv((T)a[k][i], (T)pc[i], racc[r]);
+                        cacc[i] = fma_tv((T)a[k][i], pr, cacc[i]);
                     }
                 } else {
                     const uint64_t row = r0 + r;               // (row, col): col > row both, col == row once
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        if (c + i >= row) racc[r] += a[k][i] * pc[i];
-                        if (c + i > row) cacc[i] += a[k][i] * pr;
+                        if (c + i >= row) racc[r] = fma_tv((T)a[k][i], (T)pc[i], racc[r]);
+                        if (c + i > row) cacc[i] = fma_tv((T)a[k][i], pr, cacc[i]);
                     }
                 }
             }
