@@ -820,3 +820,15 @@ def test_persistent_launch_is_bit_identical_to_the_two_launch_chain(lam, dtype_n
             assert st["t_gemv"] > 0
             res.append(out + (s.solution().tobytes(), st["rel_err"]))
     assert res[0] == res[1] == res[2] == res[3]
+
+
+def test_fuzz_bit_preserving_options():
+    """tools/fuzz_options.py: 150 random (dtype, N, shards, iterations, call pattern) cases, each solved with the default
+    options and with a random mix of the options that only change HOW an iteration is launched and enqueued (fused /
+    two-kernel vector step, in-kernel / separate reduction, event sampling, enqueue threads, hub, persistent launch and
+    its chunking): every case must give the same bits (round-3 builder run: 800 of 800)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_options.py"), "150", "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "150 of 150 cases" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

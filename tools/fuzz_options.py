@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the launch / enqueue options that must not change a single bit: for random (dtype, N,
+shards, seed) the solve with default options against the solve with a random combination of fuse_update, finalize,
+host_threads, exchange_hub, gemv_timing, persistent / persist_chunk, and the solve cut into random cg_iterate chunks.
+Also compares with the CPU oracle at a tolerance.   usage: fuzz_options.py [cases] [seed]"""
+import importlib
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
+
+
+def run(dt, n, shards, seed, opts, chunks):
+    with lam.Solver(dt, device_ids=[0] * shards) as s:
+        s.generate_random_spd(n, seed, 500.0)
+        s.generate_random_rhs(seed + 1)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.cg_init()
+        st = None
+        for c in chunks:
+            st = s.cg_iterate(c, 0.0)
+        eff = {k: s.get_option(k) for k in ("fuse_effective", "persistent_effective")}
+        return s.solution(), st["rel_err"], st["num_iters"], eff, s.true_residual()
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for case in range(cases):
+        dt, dname = rng.choice(((lam.F64, "f64"), (lam.F64, "f64"), (lam.F32, "f32"), (lam.BF16, "bf16")))
+        shards = rng.choice((1, 1, 1, 2, 3, 5))
+        n = rng.choice((rng.randint(shards * 2, 300), rng.randint(300, 9000), rng.choice((256, 1024, 4096, 4098, 8192, 10000))))
+        n = max(n, shards)
+        total = rng.randint(1, 60)
+        seed = rng.randint(1, 10 ** 6)
+        ref = run(dt, n, shards, seed, {}, [total])
+        opts = {"fuse_update": rng.choice((0, 1)), "finalize": rng.choice((1, 1, 0)), "gemv_timing": rng.choice((0, 1, 3, 8)),
+                "host_threads": rng.choice((0, 1)), "exchange_hub": rng.choice((0, 1)), "persistent": rng.choice((0, 1)),
+                "persist_chunk": rng.choice((1, 2, 7, 32))}
+        chunks, left = [], total
+        while left > 0:
+            c = rng.randint(1, left)
+            chunks.append(c)
+            left -= c
+        got = run(dt, n, shards, seed, opts, chunks)
+        same = np.array_equal(ref[0], got[0]) and ref[1] == got[1] and ref[2] == got[2]
+        finite = bool(np.all(np.isfinite(got[0])))
+        res_ok = abs(got[4] - got[1]) <= 1e-6 * max(got[1], 1e-30) + (1e-12 if dname == "f64" else 1e-4)
+        ok = same and finite and res_ok
+        bad += not ok
+        print(f"{'ok  ' if ok else 'FAIL'} case {case}: {dname} N={n} shards={shards} iters={total} chunks={chunks} opts={opts} "
+              f"effective={got[3]} rel_err={got[1]:.3e} true={got[4]:.3e}", flush=True)
+    print(f"# {cases - bad} of {cases} cases bit-identical to the default options")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
