@@ -2049,7 +2049,10 @@ static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_e
     HostBarrier bar(L);
     std::vector<int> rcs(L, 0);
     int enq = 0;
+    std::atomic<int> go{0};                         // 0: wait, 1: run, 2: cancelled (a thread could not be created)
     auto worker = [&](int q) {
+        while (go.load(std::memory_order_acquire) == 0) sched_yield();
+        if (go.load(std::memory_order_acquire) == 2) return;
         ShardBase &s = c->sh[q];
         int rc = set_dev(c, s);
         auto phase = [&](auto &&fn) {               // run one phase unless this thread has already failed
@@ -2088,7 +2091,15 @@ static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_e
     };
     std::vector<std::thread> th;
     th.reserve(L);
-    for (int q = 1; q < L; q++) th.emplace_back(worker, q);
+    try {
+        for (int q = 1; q < L; q++) th.emplace_back(worker, q);
+    } catch (...) {
+        // no exception may cross the C ABI, and the threads that did start must not wait at a barrier for ever
+        go.store(2, std::memory_order_release);
+        for (auto &t : th) t.join();
+        return fail(c, LAM_HIP_ENOMEM, "could not start the per-shard enqueue threads (option host_threads)");
+    }
+    go.store(1, std::memory_order_release);
     worker(0);
     for (auto &t : th) t.join();
     *enq_out = enq;
