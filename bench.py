@@ -212,6 +212,7 @@ def main():
                     help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes (roofline.traffic then "
                     "comes from profiles/traffic.json, tagged as such)")
+    ap.add_argument("--gemv-timing", type=int, default=4, help="time the GEMV of every T-th iteration with a HIP-event pair")
     ap.add_argument("--ramp", type=float, default=0.6, help="seconds of untimed GEMV launches before the warm-up steps of the headline "
                     "(device clock ramp, see clock_ramp); 0 = none")
     ap.add_argument("--config4-n", type=int, default=131072, help="matrix order of the configs[3] GEMV-only side run")
@@ -278,6 +279,9 @@ def main():
 
     n = args.n
     s = make_solver()
+    # t_gemv (roofline.achieved) = average of HIP-event pairs around the GEMV launch of every 4th iteration of the timed steps
+    # (library default: every 8th; each record is a marker packet in the stream, ~2 us per iteration at this rate)
+    s.set_option("gemv_timing", args.gemv_timing)
     # HEADLINE = the product's default configuration of this topology (rank mode: lam_hip's default exchange), whatever
     # the other exchange modes measure below; they are recorded under "exchange_modes" only.
     default_exchange = s.get_option("exchange") if use_dist else None
@@ -504,6 +508,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "timing": f"HIP-event pair around the GEMV launch of every {args.gemv_timing}th iteration of the timed steps, on the launch stream",
                      "algorithmic_bytes_per_launch": gemv_bytes},
         "host_plumbing": {"torch_imported": "torch" in sys.modules,
                           "rendezvous": "package socket rendezvous (_rendezvous.py)" if rdzv else None,
