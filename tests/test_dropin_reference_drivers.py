@@ -61,7 +61,7 @@ def test_reference_positional_driver_runs_on_hip_classes(name, golden, oracle, t
     assert r.returncode == 0, r.stdout + r.stderr
     x = oracle.read_bin(str(sol)).reshape(-1)
     x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
-    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 10 * g["tol"]   # 1e-8 at tol 1e-9
 
 
 @pytest.mark.gpu

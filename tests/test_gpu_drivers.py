@@ -61,7 +61,7 @@ def test_getopt_driver_file_mode_against_golden_solution(golden, oracle, tmp_pat
     assert float(f[8]) < g["tol"]
     x = oracle.read_bin(str(sol)).reshape(-1)
     x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
-    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 10 * g["tol"]   # 1e-8 at tol 1e-9
 
 
 @pytest.mark.parametrize("exe,env", [(ONE_EXE, {}), (MULTI_EXE, {"LAM_NUM_SHARDS": "3"}),
@@ -84,7 +84,7 @@ def test_positional_drivers(golden, oracle, tmp_path, exe, env):
             line = next(l for l in r.stdout.splitlines() if l.startswith("Converged in"))
             k = int(line.split()[2])
             assert abs(k - g["iters_printed"]) <= max(3, 0.02 * g["iters_printed"])
-            assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+            assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 10 * g["tol"]   # 1e-8 at tol 1e-9
         else:
             assert f"Did not converge in {g['max_iters']} iterations" in r.stdout
             assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-12
@@ -291,7 +291,7 @@ def test_env_launched_driver_multi_rank(tmp_path, mock_mp_lib, golden, oracle, e
     assert all(o[0].strip() == "" for o in outs[1:])                    # only rank 0 prints the CSV
     x = oracle.read_bin(str(sol)).reshape(-1)
     x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
-    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 10 * g["tol"]   # 1e-8 at tol 1e-9
     assert not os.path.exists(tmp_path / "id")                          # rank 0 removed the rendezvous file
 
 

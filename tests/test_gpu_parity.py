@@ -12,7 +12,8 @@ Tolerances (fp64; SURVEY.md section 8c, from the reference's own run-to-run spre
                       files show 358 vs 359 and 306 vs 307-308 for identical inputs.
   CG final residual   printed recursive residual < tol, true residual ||b-Ax||/||b|| <= 2*tol (+1e-13)
   CG solution         ||x - x_ref||_2 <= (||b-Ax|| + ||b-Ax_ref||) / lambda_min(A)  (rigorous, since
-                      x - x_ref = A^-1 (r_ref - r)), and <= 1e-6 relative; fixed-iteration runs 1e-9
+                      x - x_ref = A^-1 (r_ref - r)), and <= 10*tol relative (1e-8 at tol 1e-9, the survey's figure;
+                      measured <= 1.1e-10); fixed-iteration runs 1e-12
   generate mode       printed error equal to the reference CSV value to its 6 printed digits (<= 5e-6 rel)
 """
 import math
@@ -108,7 +109,8 @@ def _check_against_golden(lam, oracle, g, shards):
         bound = (res + np.linalg.norm(b - A @ x_ref)) / lam_min
         err = np.linalg.norm(x - x_ref)
         assert err <= 1.01 * bound, (g["tag"], err, bound)
-        assert err / np.linalg.norm(x_ref) <= 1e-6, (g["tag"], err)
+        # ... and SURVEY 8c's figure: 1e-8 relative at tol 1e-9 on these cond ~1e3 fixtures (= 10 x tol; measured: <= 1.1e-10)
+        assert err / np.linalg.norm(x_ref) <= 10 * g["tol"], (g["tag"], err)
     else:
         # fixed iteration count, far from convergence: everything is well conditioned
         assert st["num_iters"] == g["max_iters"] + 1
