@@ -65,8 +65,12 @@ struct ShardBase {
     void *p = nullptr;           // n (replica)
     void *Ap = nullptr, *x = nullptr, *r = nullptr, *b = nullptr;  // nrows each
     void *tmp = nullptr;         // n: scratch vector (gemv op input / residual)
-    void *r_full = nullptr;      // n: replicated r (rank mode, gather-Ap exchange only)
-    void *ap_gather = nullptr;   // nranks records [Ap slice | double]: gather-Ap exchange only
+    void *r_full = nullptr;      // n: replicated r (gather-Ap exchange only)
+    void *ap_gather = nullptr;   // P records [Ap slice | double]: gather-Ap exchange only.  One process with several shards:
+                                 // TWO such buffers back to back (iteration parity), because there the producers store into
+                                 // their peers' buffers themselves and a shard may start the next GEMV while a slower peer is
+                                 // still reading this iteration's records (ap_gather_bytes = one buffer)
+    size_t ap_gather_bytes = 0;
     void *symv_rowpart = nullptr, *symv_colpart = nullptr;   // symmetric product (option "symmetric")
     SymvTask *symv_tasks = nullptr;
     int symv_ntasks = 0;
@@ -120,7 +124,12 @@ struct lam_hip_ctx {
     int64_t opt_panel_lo = 0, opt_panel_hi = 0;  // testing: split the CG GEMV into [lo,hi) + the rest
     bool gather_pending = false;   // an all-gather of p is in flight on comm_stream
     int64_t opt_symmetric = 0;     // single shard: read only the upper triangle (caller asserts A == A^T)
-    int64_t opt_exchange = 0;      // rank mode: 0 = all-gather x2 (8 B/rank) + all-gather(p); 1 = one all-gather of [Ap | p.Ap]
+    int64_t opt_exchange = 0;      // 0 = sliced vectors, three exchanges per iteration (p.Ap, r.r, p slices); 1 = gather-Ap: ONE
+                                   // exchange of [Ap slice | p.Ap partial] per iteration, r and p full-length on every shard;
+                                   // 2 = direct (in-kernel flags)
+    int64_t opt_join = 1;          // one process, gather-Ap: 1 = the iteration's single join goes through shard 0's stream (it
+                                   // waits for the other shards' posts and records ONE join event they wait for: 2(P-1)+1
+                                   // runtime calls); 0 = every stream waits for every other one (P(P-1) calls)
     int64_t opt_fuse = 1;          // one shard / direct exchange: x, r and p updates in ONE launch (update_fused_kernel)
     int64_t opt_reuse_matrix = 1;  // lam_hip_set_problem keeps (and re-uses) the matrix allocation when it is large enough
     int64_t opt_upload_staging = 0; // lam_hip_upload_rows: 1 = pipeline through two pinned staging buffers
@@ -177,13 +186,14 @@ struct lam_hip_ctx {
         return opt_symmetric && !rank_mode && total_shards == 1 && dtype != LAM_HIP_BF16 && n > 0 && n % symv_tile() == 0;
     }
 
-    // gather-Ap needs equal slices and an 8-byte aligned tail for the double
     bool exchange2_wanted() const { return (rank_mode || total_shards > 1) && opt_exchange == 2 && opt_finalize != 0; }
+    // gather-Ap needs equal slices and an 8-byte aligned tail for the double (total_shards == nranks in rank mode)
     bool exchange1_ok() const
     {
-        return rank_mode && opt_exchange == 1 && n % (uint64_t)nranks == 0 && ((n / (uint64_t)nranks) * esz_v()) % 8 == 0;
+        return (rank_mode || total_shards > 1) && opt_exchange == 1 && n % (uint64_t)total_shards == 0 &&
+               ((n / (uint64_t)total_shards) * esz_v()) % 8 == 0;
     }
-    uint64_t ex1_base() const { return n / (uint64_t)nranks; }
+    uint64_t ex1_base() const { return n / (uint64_t)total_shards; }
     uint64_t ex1_stride_bytes() const { return ex1_base() * esz_v() + 8; }
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
@@ -448,11 +458,15 @@ struct Impl {
     }
 
     static int launch_gemv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc,
-                           int panel = 0, uint64_t lo = 0, uint64_t hi = 0, const Finalize *fin = nullptr)
+                           int panel = 0, uint64_t lo = 0, uint64_t hi = 0, const Finalize *fin = nullptr, const PtrList *ypeers = nullptr)
     {
         if (s.nrows == 0) return 0;
         GemvArgs<TA, TV> a;
         a.A = (const TA *)s.A; a.p = p; a.y = y; a.partial = partial; a.sc = sc;
+        a.n_ypeer = 0;
+        for (auto &yp : a.ypeer) yp = nullptr;
+        if (ypeers != nullptr)
+            for (int j = 0; j < ypeers->n && a.n_ypeer < kMaxShards - 1; j++) a.ypeer[a.n_ypeer++] = (TV *)ypeers->p[j];
         if (fin != nullptr && partial != nullptr) a.fin = *fin;
         else { a.fin.active = 0; a.fin.mail = 0; a.fin.seq = 0; a.fin.dst.n = 0; a.fin.slot = 0; a.fin.host_err = c->direct_err; }
         a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
@@ -1216,9 +1230,113 @@ int enqueue_iteration_direct(lam_hip_ctx *c, int k, double rel_error, int slot)
     });
 }
 
+// gather-Ap exchange, one process with several shards: CG state = x slice, FULL r and p on every shard.  The rhs
+// slices are replicated once with peer copies (the rank mode's one-off all-gather), after that no vector is exchanged
+// but Ap.
+int do_cg_init_exchange1_local(lam_hip_ctx *c)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        const size_t ev = c->esz_v();
+        LAMCHK(sync_all(c));
+        for (auto &dst : c->sh) {
+            LAMCHK(set_dev(c, dst));
+            for (auto &src : c->sh)
+                HIPCHK(c, hipMemcpyAsync((char *)dst.r_full + src.row0 * ev, src.b, src.nrows * ev, hipMemcpyDefault, dst.stream));
+        }
+        const int grid = vec_grid(c->n);
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            hipLaunchKernelGGL((cg_init_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (TV *)s.r_full, (TV *)s.p,
+                               (TV *)s.x, c->n, s.nrows, s.part_vec);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(cg_init_scalars_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc);
+            HIPCHK(c, hipGetLastError());
+        }
+        LAMCHK(arm_partials(c));
+        c->k_done = 0;
+        c->cg_ready = true;
+        c->cg_exchange1 = true;
+        return 0;
+    });
+}
+
+// One iteration on the gather-Ap exchange with several shards in one process (the reference's CPU path gathers Ap too,
+// ConjugateGradient_CPU_MPI_OMP.hpp:505; the single-process CUDA class gathers it on device 0,
+// ConjugateGradient_MultiGPUS_CUDA.cu:362-376).  Per shard: the GEMV stores every row of its Ap slice into its record in
+// EVERY shard's gather buffer (peer stores over xGMI) and its reducer workgroup does the same with the shard's p.Ap
+// partial; one event record.  Then the iteration's ONLY join -- through shard 0's stream (2(P-1)+1 runtime calls) or
+// all-to-all (P(P-1)) -- and the two full-length vector kernels, which need nothing from the peers any more: r.r is the
+// same sum on every shard.  Same kernels, same arithmetic as the rank mode's exchange 1: bit-identical to it.
+// The gather buffer is double (iteration parity): shard q may start GEMV k+1 -- which stores into its peers' buffers --
+// as soon as ITS update of iteration k is done, while a slower peer still reads the records of iteration k; GEMV k+2
+// cannot start before every peer has finished GEMV k+1, i.e. its update k.
+int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, int slot)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using I = decltype(impl);
+        using TV = typename ImplTraits<I>::TV;
+        const int P = c->total_shards;
+        const uint64_t stride = c->ex1_stride_bytes(), base = c->ex1_base();
+        auto buf = [&](ShardBase &t) { return (char *)t.ap_gather + (size_t)(k & 1) * t.ap_gather_bytes; };
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            const uint64_t off = (uint64_t)s.index * stride;
+            Finalize f = no_finalize(c);
+            f.active = c->opt_finalize ? 1 : 0;
+            f.slot = 0;
+            f.dst.n = P;
+            PtrList yp;
+            yp.n = 0;
+            for (auto &t : c->sh) {
+                f.dst.p[t.index] = buf(t) + off + base * sizeof(TV);
+                if (&t != &s) yp.p[yp.n++] = buf(t) + off;
+            }
+            const bool timed = timed_iteration(c, s, k);
+            s.split_slot[slot] = false;
+            s.timed_slot[slot] = timed;
+            if (timed) RECORD(c, s.ev_g0[slot], s.stream);
+            LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)(buf(s) + off), s.part_gemv, s.sc, 0, 0, 0, &f, &yp));
+            if (timed) RECORD(c, s.ev_g1[slot], s.stream);
+            if (!c->opt_finalize) {
+                hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, s.gemv_blocks,
+                                   f.dst, 0, (const CgScalars *)s.sc);
+                LAUNCHED(c);
+            }
+            if (!(c->opt_join && &s == &c->sh[0])) RECORD(c, s.ev_a, s.stream);
+        }
+        // the join
+        if (c->opt_join) {
+            ShardBase &s0 = c->sh[0];
+            LAMCHK(set_dev(c, s0));
+            for (auto &t : c->sh)
+                if (&t != &s0) WAITEV(c, s0.stream, t.ev_a);
+            RECORD(c, c->ev_join[0], s0.stream);
+        }
+        const int grid = vec_grid(c->n);
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            if (c->opt_join) {
+                if (&s != &c->sh[0]) WAITEV(c, s.stream, c->ev_join[0]);
+            } else {
+                for (auto &t : c->sh)
+                    if (&t != &s) WAITEV(c, s.stream, t.ev_a);
+            }
+            hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)buf(s), stride,
+                               base, P, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
+            LAUNCHED(c);
+            hipLaunchKernelGGL((update_p_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc,
+                               k, rel_error, (const TV *)s.r_full, (TV *)s.p, c->n, (volatile int *)s.host_flags);
+            LAUNCHED(c);
+        }
+        return 0;
+    });
+}
+
 // gather-Ap exchange: CG state = x slice, FULL r and p on every rank
 int do_cg_init_exchange1(lam_hip_ctx *c)
 {
+    if (!c->rank_mode) return do_cg_init_exchange1_local(c);
     return dispatch(c, [&](auto impl) -> int {
         using TV = typename ImplTraits<decltype(impl)>::TV;
         ShardBase &s = c->sh[0];
@@ -1242,6 +1360,7 @@ int do_cg_init_exchange1(lam_hip_ctx *c)
 
 int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
+    if (!c->rank_mode) return enqueue_iteration_exchange1_local(c, k, rel_error, slot);
     return dispatch(c, [&](auto impl) -> int {
         using I = decltype(impl);
         using TV = typename ImplTraits<I>::TV;
@@ -1638,7 +1757,7 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
         c->sh[q].dev = device_ids ? device_ids[q] : q % ndev;
     }
     // default exchange of this context (only 0 and 2 mean something with several shards in one process)
-    if (const char *ex = getenv("LAM_HIP_EXCHANGE")) c->opt_exchange = atoi(ex) == 2 ? 2 : 0;
+    if (const char *ex = getenv("LAM_HIP_EXCHANGE")) { const int v = atoi(ex); c->opt_exchange = (v == 1 || v == 2) ? v : 0; }
     int rc = create_common(c.get());
     if (rc != 0) { abandon(c.get()); return rc; }
     *out = c.release();
@@ -1775,9 +1894,11 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         HIPCHK(c, hipMalloc((void **)&s.part_aux, sizeof(double) * kVecBlocksMax));
         HIPCHK(c, hipMalloc((void **)&s.gather_a, sizeof(double) * kMaxShards));
         HIPCHK(c, hipMalloc((void **)&s.gather_b, sizeof(double) * kMaxShards));
-        if (c->rank_mode) {
+        if (c->rank_mode || c->total_shards > 1) {
+            // gather-Ap exchange (option exchange = 1): full-length r, and the records [Ap slice | p.Ap partial] of all shards
             HIPCHK(c, hipMalloc(&s.r_full, n * ev + 16));
-            HIPCHK(c, hipMalloc(&s.ap_gather, (size_t)c->nranks * ((n / (uint64_t)c->nranks + 1) * ev + 8) + 16));
+            s.ap_gather_bytes = ((size_t)c->total_shards * ((n / (uint64_t)c->total_shards + 1) * ev + 8) + 16 + 255) / 256 * 256;
+            HIPCHK(c, hipMalloc(&s.ap_gather, s.ap_gather_bytes * (c->rank_mode ? 1 : 2)));
         }
         HIPCHK(c, hipMalloc((void **)&s.sc, sizeof(CgScalars)));
         HIPCHK(c, hipHostMalloc((void **)&s.sc_host, sizeof(CgScalars), hipHostMallocDefault));
@@ -2592,6 +2713,7 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "probe_rows")) c->opt_probe_rows = value;
     else if (!strcmp(name, "overlap")) c->opt_overlap = value;
     else if (!strcmp(name, "exchange")) { c->opt_exchange = value; c->cg_ready = false; }
+    else if (!strcmp(name, "exchange_join")) c->opt_join = value;
     else if (!strcmp(name, "finalize")) { c->opt_finalize = value; c->cg_ready = false; }
     else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
     else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
@@ -2622,6 +2744,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "probe_rows")) *value = c->opt_probe_rows;
     else if (!strcmp(name, "overlap")) *value = c->opt_overlap;
     else if (!strcmp(name, "exchange")) *value = c->opt_exchange;
+    else if (!strcmp(name, "exchange_join")) *value = c->opt_join;
     else if (!strcmp(name, "finalize")) *value = c->opt_finalize;
     else if (!strcmp(name, "upload_staging")) *value = c->opt_upload_staging;
     else if (!strcmp(name, "reuse_matrix")) *value = c->opt_reuse_matrix;

@@ -428,7 +428,19 @@ struct GemvArgs {
     int nseg;
     int accumulate;         // y[row] += ... instead of y[row] = ...
     Finalize fin;           // in-kernel reduction of `partial` by the last workgroup (several shards)
+    // gather-Ap exchange with several shards in one process: y[row] also goes, as a peer store over xGMI, to the same
+    // row of this shard's record in every OTHER shard's gather buffer (n_ypeer = 0 everywhere else)
+    TV *ypeer[kMaxShards - 1];
+    int n_ypeer;
 };
+
+// the row's result: the shard's own copy and the peers' (see GemvArgs::ypeer)
+template <typename TA, typename TV>
+__device__ __forceinline__ void store_y(const GemvArgs<TA, TV> &a, uint64_t row, TV v)
+{
+    a.y[row] = v;
+    for (int j = 0; j < a.n_ypeer; j++) a.ypeer[j][row] = v;
+}
 
 // Fast path: n % (16/sizeof(TA)) == 0, A and p 16-byte aligned.
 //   workgroup = 4 waves, wave w owns rows (4*blockIdx+w)*R .. +R-1, all n columns.
@@ -551,7 +563,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
         const uint64_t row = row_first + r;
         if (lane == 0 && row < a.nrows) {
             if (a.accumulate) s += a.y[row];
-            a.y[row] = s;
+            store_y(a, row, s);
             dotp += (double)s * (double)a.p[a.row0 + row];
         }
     }
@@ -692,7 +704,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
 #pragma unroll
             for (int w = 1; w < WAVES; w++) s += s_part[tid][w];
             if (a.accumulate) s += a.y[row];
-            a.y[row] = s;
+            store_y(a, row, s);
             d = (double)s * (double)a.p[a.row0 + row];
         }
         s_dot[tid] = d;
@@ -836,7 +848,7 @@ gemv_coop_group_kernel(GemvArgs<TA, TV> a)
             TV sum = s_part[g][r][0];
 #pragma unroll
             for (int wv = 1; wv < WAVES; wv++) sum += s_part[g][r][wv];
-            a.y[row] = sum;
+            store_y(a, row, sum);
             d = (double)sum * (double)a.p[a.row0 + row];
         }
         s_dot[tid] = d;
@@ -978,7 +990,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
         const uint64_t row = row_first + r;
         if (lane == 0 && row < a.nrows) {
             if (a.accumulate) s += a.y[row];
-            a.y[row] = s;
+            store_y(a, row, s);
             dotp += (double)s * (double)a.p[a.row0 + row];
         }
     }
@@ -1208,7 +1220,7 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
         acc = wave_sum(acc);
         if (lane == 0) {
             if (a.accumulate) acc += a.y[row];
-            a.y[row] = acc;
+            store_y(a, row, acc);
             dotp = (double)acc * (double)a.p[a.row0 + row];
         }
     }

@@ -82,14 +82,18 @@ def test_dot_axpby_match_oracle(lam, oracle, n):
 # ------------------------------------------------------------------------------------------------
 # CG: golden fixtures produced by the reference (file mode)
 # ------------------------------------------------------------------------------------------------
-def _check_against_golden(lam, oracle, g, shards):
+def _check_against_golden(lam, oracle, g, shards, exchange=None):
     A = oracle.read_bin(os.path.join(GOLDEN, g["name"] + ".matrix.bin"))
     b = oracle.read_bin(os.path.join(GOLDEN, g["name"] + ".rhs.bin")).reshape(-1)
     x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
     with lam.Solver(lam.F64, n_shards=shards, device_ids=[0] * shards) as s:
         assert s.load_matrix_from_file(os.path.join(GOLDEN, g["name"] + ".matrix.bin"))
         assert s.load_rhs_from_file(os.path.join(GOLDEN, g["name"] + ".rhs.bin"))
+        if exchange is not None:
+            s.set_option("exchange", exchange)
         converged = s.solve(g["max_iters"], g["tol"])
+        if exchange is not None:
+            assert s.get_option("exchange_effective") == exchange
         st = s.stats
         x = s.solution()
         true_res = s.true_residual()
@@ -631,6 +635,58 @@ def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
                 s.cg_iterate(chunk, 0.0)
             res.append(out + (s.solution().tobytes(), s.stats["rel_err"]))
     assert res[0] == res[1] == res[2] == res[3]
+
+
+@pytest.mark.parametrize("shards,n,dtype_name", [(2, 1024, "F64"), (4, 4096, "F64"), (8, 8192, "F64"), (3, 3000, "F64"), (8, 4104, "F64"),
+                                                  (4, 2048, "F32"), (2, 1000, "F64"), (5, 1000, "F64")])
+def test_one_process_gather_ap_exchange(lam, shards, n, dtype_name):
+    """One process, several shards, option exchange = 1 (gather-Ap): every shard's GEMV stores its Ap slice and its p.Ap
+    partial straight into every shard's gather buffer, ONE join per iteration (through shard 0's stream, or all-to-all
+    with exchange_join 0), r and p full-length on every shard (the reference CPU path's layout,
+    ConjugateGradient_CPU_MPI_OMP.hpp:476,505).  Both joins give the same bits, also when the solve is cut into calls;
+    the result agrees with the three-exchange default to the recursion's sensitivity, its recomputed residual meets
+    the tolerance, and sizes the exchange cannot take (N not a multiple of the shard count) run on exchange 0."""
+    dt = getattr(lam, dtype_name)
+    tol = 1e-9 if dtype_name == "F64" else 1e-5
+    res = {}
+    for label, exchange, join in (("events", 0, 1), ("gather_ap", 1, 1), ("gather_ap_all_to_all", 1, 0)):
+        with lam.Solver(dt, device_ids=[0] * shards) as s:
+            s.generate_random_spd(n, 7, 200.0)
+            s.generate_random_rhs(8)
+            s.set_option("exchange", exchange)
+            s.set_option("exchange_join", join)
+            s.solve(500, tol)
+            assert s.stats["converged"]
+            eff = s.get_option("exchange_effective")
+            out = dict(iters=s.stats["num_iters"], err=s.stats["rel_err"], x=s.solution(), res=s.true_residual(), eff=eff)
+            s.cg_init()
+            for chunk in (1, 2, 9, 30):
+                s.cg_iterate(chunk, 0.0)
+            out["x42"], out["err42"] = s.solution(), s.stats["rel_err"]
+            res[label] = out
+    a, b, e = res["gather_ap"], res["gather_ap_all_to_all"], res["events"]
+    assert a["eff"] == b["eff"] == (1 if n % shards == 0 else 0) and e["eff"] == 0
+    for k in ("iters", "err", "err42"):
+        assert a[k] == b[k], k
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["x42"], b["x42"])
+    if a["eff"] == 0:                                   # fell back: the very same path as the default
+        assert np.array_equal(a["x"], e["x"]) and a["iters"] == e["iters"]
+    assert abs(a["iters"] - e["iters"]) <= 2
+    assert a["res"] <= 2 * tol + 1e-13 and a["err"] < tol
+    assert np.linalg.norm(a["x"] - e["x"]) / np.linalg.norm(e["x"]) <= (1e-8 if dtype_name == "F64" else 1e-3)
+    assert np.linalg.norm(a["x42"] - e["x42"]) / np.linalg.norm(e["x42"]) <= (1e-9 if dtype_name == "F64" else 1e-3)
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_one_process_gather_ap_file_mode_golden(lam, oracle, golden, shards):
+    """The reference's own fixtures on the gather-Ap exchange (same gates as test_cg_file_mode_golden)."""
+    ran = 0
+    for g in golden["file_mode"]:
+        if g["n"] % shards != 0:
+            continue
+        _check_against_golden(lam, oracle, g, shards, exchange=1)
+        ran += 1
+    assert ran >= 3
 
 
 def test_gemv_timing_can_be_sampled_or_off(lam):

@@ -98,6 +98,29 @@ def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, ov
         assert out["collectives_enqueued"][0] < 40 + 4 * P, out
 
 
+@pytest.mark.parametrize("P,n", [(2, 1024), (4, 4096), (8, 8192)])
+def test_one_process_gather_ap_is_bit_identical_to_rank_mode_gather_ap(mock_async, tmp_path, P, n):
+    """exchange 1 exists in both multi-GPU topologies: one process per GPU (ONE ncclAllGather of [Ap slice | p.Ap partial]
+    per iteration) and one process driving all shards (the GEMV stores the records into the peers' buffers itself, one
+    event join).  Same kernels, same arithmetic: iteration count, residual and every bit of x must agree."""
+    import hashlib
+    import importlib
+    r, out, lines = _run(mock_async, tmp_path, P, n, "spd", "--exchange", 1, "--no-single")
+    _check_mock_stats(lines, P)
+    assert out["exchange_effective"] == [1] * P
+    lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
+    for join in (1, 0):
+        with lam.Solver(lam.F64, device_ids=[0] * P) as s:
+            s.generate_random_spd(n, 99, 200.0)          # run_ranks.py's system
+            s.generate_random_rhs(100)
+            s.set_option("exchange", 1)
+            s.set_option("exchange_join", join)
+            s.solve(2000, 1e-10)
+            assert s.get_option("exchange_effective") == 1
+            got = (s.stats["num_iters"], s.stats["rel_err"], hashlib.sha256(s.solution().tobytes()).hexdigest())
+        assert got == (out["iters"], out["rel_err"], out["x_sha"]), (join, got, out)
+
+
 @pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), (4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
 def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path, P, n, mode):
     """exchange 2 sums the ranks' partial dot products with the same reduction tree as exchange 0, so the

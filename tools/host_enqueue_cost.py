@@ -43,15 +43,24 @@ def main():
         with lam.Solver(lam.F64, device_ids=[0] * P) as s:
             s.generate_random_spd(n, 11, 1e6)
             s.generate_random_rhs(12)
+            tuning = s.get_option("tuning_variants") == 1       # host_threads / exchange_hub exist in the tuning build only
             for threads, hub, timing, exchange, overlap in ((0, 0, 1, 0, 1), (0, 0, 0, 0, 1), (1, 0, 0, 0, 1), (0, 1, 0, 0, 1), (1, 1, 0, 0, 1),
-                                                            (0, 0, 0, 2, 1), (0, 0, 0, 2, 0)):
-                if P == 1 and (threads == 1 or hub == 1 or exchange == 2):
+                                                            (0, 0, 0, 1, 1), (0, 0, 0, 1, 0), (0, 0, 0, 2, 1), (0, 0, 0, 2, 0)):
+                if P == 1 and (threads == 1 or hub == 1 or exchange != 0):
                     continue
-                s.set_option("host_threads", threads)
-                s.set_option("exchange_hub", hub)
+                if (threads or hub) and not tuning:
+                    continue
+                if exchange == 1 and n % P != 0:
+                    continue
+                if tuning:
+                    s.set_option("host_threads", threads)
+                    s.set_option("exchange_hub", hub)
                 s.set_option("gemv_timing", timing)
                 s.set_option("exchange", exchange)
-                s.set_option("overlap", overlap)
+                if exchange == 1:
+                    s.set_option("exchange_join", overlap)      # gather-Ap: 1 = join through shard 0's stream, 0 = all-to-all waits
+                else:
+                    s.set_option("overlap", overlap)
                 best, per = None, None
                 for _ in range(3):
                     s.cg_init()
@@ -66,9 +75,11 @@ def main():
                 x = s.solution()
                 if ref is None:
                     ref = x
-                # the own-slice GEMV panel of "exchange 2 split" adds a row's products in another order: equal to rounding
-                same = bool(np.array_equal(x, ref)) or (exchange == 2 and overlap == 1 and np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref))
-                print(f"P={P} exchange={s.get_option('exchange_effective')}{'' if exchange != 2 else (' split' if overlap else ' nosplit')} host_threads={threads} exchange_hub={hub} gemv_timing={timing}: HOST {host:7.1f} us/iteration to enqueue, wall {best*1e6:7.1f} us/iteration   calls/iteration: "
+                # the own-slice GEMV panel of "exchange 2 split" adds a row's products in another order, gather-Ap sums r.r over
+                # full-length partials: equal to rounding
+                same = bool(np.array_equal(x, ref)) or ((exchange == 1 or (exchange == 2 and overlap == 1)) and np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref))
+                kind = {0: "", 1: " gather-Ap join-via-shard0" if overlap else " gather-Ap all-to-all", 2: " split" if overlap else " nosplit"}[exchange]
+                print(f"P={P} exchange={s.get_option('exchange_effective')}{kind} host_threads={threads} exchange_hub={hub} gemv_timing={timing}: HOST {host:7.1f} us/iteration to enqueue, wall {best*1e6:7.1f} us/iteration   calls/iteration: "
                       + " ".join(f"{k}={per[k]:.1f}" for k in CALLS) + f"   same result as first variant: {same}", flush=True)
                 assert same
 
