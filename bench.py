@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "2024-eumaster4hpc-student-challenge_amd"
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+MFMA_VARIANTS = ((21, "MFMA v_mfma_f32_32x32x16_bf16, p as 3 bf16 terms"), (20, "MFMA, p rounded to bf16"))
 ALSO_SIZES = (32768, 10000, 20000, 40000)
 
 
@@ -98,14 +99,51 @@ def cpu_baseline(sample_n, iters):
             "gemv_gbps": 8.0 * sample_n * sample_n / (st["t_gemv"] / iters) / 1e9, "sample_n": sample_n}
 
 
-def clock_ramp(s, seconds):
+def settle(s, seconds):
     """Untimed set-up, like the matrix generation: keep the device busy with GEMV launches for `seconds` before the
-    warm-up steps.  An MI355X that has just been idle serves the first ~0.3 s of sustained load at a lower memory-clock
-    level (same launch: 5.02 ms, later 4.815 ms -- profiles/r03_clock_ramp.txt); a timed region of 0.1-0.5 s that
-    starts 60 ms after the first touch would measure that transient, not the rate a solve runs at."""
+    warm-up steps.  What it waits out is NOT a clock ramp (round 3's reading): a fresh process on an idle device runs
+    its very first launches at full rate (profiles/r04_bf16_gap_probe.txt).  It is the driver wiping VRAM that another
+    process (or context) has just RELEASED: the child processes that run in front of this one (CPU baseline, two PMC
+    passes) each free 34 GB at exit, the wipe runs in the background and takes HBM bandwidth from whatever runs next --
+    the same GEMV measures 3-4 % slower for a second or two after a multi-GB hipFree (same file: bf16 85.5 % of peak right
+    after a 68.7 GB free, 88.4 % two seconds later and in a fresh process).  A timed region that starts inside that window
+    would measure the neighbour's clean-up, not the rate a solve runs at.  The cold number is still reported (`value_cold`)."""
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         s.gemv_only(10)
+
+
+def mfma_child(n4):
+    """BASELINE configs[3]'s MFMA comparison: the MFMA-fed bf16 GEMV shapes are experiments that lost (slower than the VALU
+    kernel) and live in the tuning build of the library only, so they are measured by a child process that loads
+    liblam_hip_tuning.so -- started before this process touches the GPU, like the other children.  Prints JSON rows."""
+    lam = importlib.import_module(PKG)
+    rows = []
+    with lam.Solver(lam.BF16) as s4:
+        s4.generate_random_spd(n4, 1234, 1e4)
+        s4.generate_random_rhs(1235)
+        s4.cg_init()
+        settle(s4, 0.3)
+        gb = (2.0 * float(n4) * n4 + 4.0 * 2 * n4) / 1e9
+        for v4, what4 in ((-1, "VALU (production), measured in the child next to the MFMA shapes"),) + MFMA_VARIANTS:
+            s4.set_option("gemv_variant", v4)
+            ts = sorted(s4.gemv_only(10) for _ in range(5))
+            rows.append({"n": n4, "dtype": "bf16", "path": what4, "kernel": s4.gemv_kernel_name(), "gemv_ms": ts[2] * 1e3, "gemv_gbps": gb / ts[2],
+                         "roofline_frac": gb / ts[2] / HBM_PEAK_GBPS, "algorithmic_bytes": gb * 1e9, "library": "liblam_hip_tuning.so (child process)"})
+    print(json.dumps(rows))
+
+
+def run_mfma_child(n4):
+    lam = importlib.import_module(PKG)
+    if not os.path.exists(lam.TUNING_LIB):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mfma-child", "--config4-n", str(n4)], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, LAM_HIP_LIB=lam.TUNING_LIB))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001
+        sys.stderr.write(f"[bench] MFMA comparison child failed: {e}\n")
+        return None
 
 
 def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=False, generate=True, ramp_s=0.0):
@@ -130,8 +168,9 @@ def run_config(s, n, warmup, steps, barrier, seed=1234, cond=1e6, symmetric=Fals
         st_c = s.cg_iterate(steps, 0.0)
         barrier()
         cold = {"value": steps / (time.perf_counter() - t0c), "gemv_ms": st_c["t_gemv"] * 1e3,
-                "what": "the same warm-up + timed steps right after the matrix generation, before the device ramp"}
-        clock_ramp(s, ramp_s)
+                "what": "the same warm-up + timed steps right after the matrix generation, before the settling launches "
+                        "(inside the window in which the driver still wipes the VRAM the child processes released)"}
+        settle(s, ramp_s)
     run_config.cold = cold
     s.cg_init()
     if warmup > 0:
@@ -214,12 +253,15 @@ def main():
                     "comes from profiles/traffic.json, tagged as such)")
     ap.add_argument("--gemv-timing", type=int, default=4, help="time the GEMV of every T-th iteration with a HIP-event pair")
     ap.add_argument("--ramp", type=float, default=0.6, help="seconds of untimed GEMV launches before the warm-up steps of the headline "
-                    "(device clock ramp, see clock_ramp); 0 = none")
+                    "(waits out the driver's wipe of VRAM released by the child processes, see settle); 0 = none")
     ap.add_argument("--config4-n", type=int, default=131072, help="matrix order of the configs[3] GEMV-only side run")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="matrix order of the CPU baseline sample (0 = the workload's own N: "
                     "no extrapolation; the reference driver needs 8*N^2 bytes of host memory)")
     ap.add_argument("--cpu-sample-iters", type=int, default=20)
+    ap.add_argument("--mfma-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.mfma_child:
+        return mfma_child(args.config4_n)
 
     # stdout carries ONE line, the JSON: native libraries print there too (RCCL writes a five-line version banner to
     # stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON
@@ -246,7 +288,9 @@ def main():
     # The one child process (the CPU baseline) goes FIRST: nothing has touched the GPU yet (a process that
     # has initialised the GPU must not fork+exec on this pool), and never under a profiler (its tool
     # library initialises the GPU before main()).
-    cb = None
+    cb, mfma_rows = None, None
+    if solo and not args.no_also and not profiled and not args.symmetric:
+        mfma_rows = run_mfma_child(args.config4_n)      # first: its 34 GB are wiped while the CPU baseline runs
     if solo and not args.no_cpu_baseline and not profiled:
         cb = cpu_baseline(args.cpu_sample_n or args.n, args.cpu_sample_iters)
     live_traffic = (None, None)
@@ -267,15 +311,18 @@ def main():
         parallelism = f"row-sharded x{world}, 1 process/GPU, RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration"
     else:
         n_gpus = max(1, args.gpus)
+        # LAM_BENCH_DEVICE_IDS="0,0" (tests on a one-GPU box): put the shards of the one-process topology on these devices
+        dev_override = [int(x) for x in os.environ.get("LAM_BENCH_DEVICE_IDS", "").split(",") if x.strip() != ""]
+        device_ids = dev_override if len(dev_override) == n_gpus else list(range(n_gpus))
 
         def make_solver():
             if n_gpus == 1:
                 return lam.Solver(lam.F64)
-            return lam.Solver(lam.F64, n_shards=n_gpus, device_ids=list(range(n_gpus)))
+            return lam.Solver(lam.F64, n_shards=n_gpus, device_ids=device_ids)
 
         def barrier():
             pass
-        parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores"
+        parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores ordered by HIP events"
 
     n = args.n
     s = make_solver()
@@ -284,10 +331,15 @@ def main():
     s.set_option("gemv_timing", args.gemv_timing)
     # HEADLINE = the product's default configuration of this topology (rank mode: lam_hip's default exchange), whatever
     # the other exchange modes measure below; they are recorded under "exchange_modes" only.
-    default_exchange = s.get_option("exchange") if use_dist else None
+    default_exchange = s.get_option("exchange") if (use_dist or n_gpus > 1) else None
+    default_join = s.get_option("exchange_join") if n_gpus > 1 and not use_dist else None
+    host_ns0 = s.get_option("host_enqueue_ns")
     st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric, ramp_s=args.ramp)
     kernel_name = s.gemv_kernel_name()
     cold_start = run_config.cold
+    effective_exchange = s.get_option("exchange_effective") if default_exchange is not None else None
+    # host time the library spent issuing one iteration of the headline configuration (its waits for the device excluded)
+    host_us_per_step = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
 
     def max_over_ranks(dt_, st_):
         if rdzv is None:
@@ -422,6 +474,70 @@ def main():
             try_direct("direct_mailboxes, no split", 0)
         s.set_option("exchange", default_exchange)
         s.set_option("overlap", 1)
+    if rdzv is None and n_gpus > 1 and not args.symmetric:
+        # ONE process driving all shards (the reference's ConjugateGradient_MultiGPUS_CUDA topology): the same problem on
+        # the same context with every exchange of this topology -- recorded for comparison, never the headline, each with
+        # the residual check against the one-GPU solve and the host time it takes to enqueue an iteration.
+        labels = {0: "events_x3 (p.Ap, r.r, p slices: three joins per iteration)", 1: "gather_Ap (one join per iteration)", 2: "direct_flags"}
+        eff_label = labels.get(effective_exchange, str(effective_exchange))
+        if effective_exchange == 1:
+            eff_label += ", join through shard 0" if default_join else ", all-to-all join"
+        ref_err = check.get("one_gpu_reference_residual")
+
+        def vs_ref(err_):
+            return abs(err_ / ref_err - 1) if ref_err else None
+
+        exchange_modes = {"default": eff_label,
+                          eff_label: {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "gemv_ms": st["t_gemv"] * 1e3,
+                                      "host_enqueue_us_per_step": host_us_per_step, "rel_residual_true": true_res, "rel_residual_recursive": st["rel_err"], "vs_one_gpu": vs_ref(st["rel_err"])}}
+
+        def timed_local(label, experimental=False, **opts):
+            if label in exchange_modes:
+                return
+            try:
+                for k_, v_ in opts.items():
+                    s.set_option(k_, v_)
+                s.cg_init()
+                want = opts.get("exchange")
+                if want is not None and s.get_option("exchange_effective") != want:
+                    raise RuntimeError(f"exchange {want} is not available for this configuration (N % shards, shared devices, peer mappings)")
+                if args.warmup > 0:
+                    s.cg_iterate(args.warmup, 0.0)
+                h0_ = s.get_option("host_enqueue_ns")
+                t0_ = time.perf_counter()
+                st_ = s.cg_iterate(args.steps, 0.0)
+                dt_ = time.perf_counter() - t0_
+                h1_ = s.get_option("host_enqueue_ns")
+                res_ = s.true_residual()
+                rec = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
+                       "host_enqueue_us_per_step": (h1_ - h0_) / args.steps * 1e-3, "rel_residual_true": res_,
+                       "rel_residual_recursive": st_["rel_err"], "vs_one_gpu": vs_ref(st_["rel_err"])}
+                if experimental:
+                    rec["experimental"] = True
+                if not (abs(res_ / st_["rel_err"] - 1) < 1e-6 and (rec["vs_one_gpu"] is None or rec["vs_one_gpu"] < 1e-9)):
+                    rec["error"] = "residual differs from the one-GPU solve: WRONG RESULT on this hardware"
+                exchange_modes[label] = rec
+            except Exception as e:   # noqa: BLE001
+                exchange_modes[label] = {"error": str(e)[:300]}
+
+        timed_local(labels[1] + ", join through shard 0", exchange=1, exchange_join=1)
+        timed_local(labels[1] + ", all-to-all join", exchange=1, exchange_join=0)
+        timed_local(labels[0], exchange=0)
+        sys.stderr.write("[bench] provisional (before the in-kernel flag exchange runs): " + json.dumps(
+            {"value": args.steps / dt if not failures else None, "n_gpus": n_gpus, "ms_per_step": dt / args.steps * 1e3,
+             "self_check": check, "exchange_modes": exchange_modes}) + "\n")
+        sys.stderr.flush()
+        if os.environ.get("LAM_BENCH_DIRECT", "1") != "0":
+            # last: an expired in-kernel wait leaves the context unusable (the error is recorded, the headline stands)
+            timed_local(labels[2] + ", own-slice panel first", experimental=True, exchange=2, overlap=1)
+            if "error" not in exchange_modes[labels[2] + ", own-slice panel first"]:
+                timed_local(labels[2] + ", no split", experimental=True, exchange=2, overlap=0)
+        try:
+            s.set_option("exchange", default_exchange)
+            s.set_option("exchange_join", default_join)
+            s.set_option("overlap", 1)
+        except Exception:   # noqa: BLE001
+            pass
     dt, st, true_res, parallelism = headline["dt"], headline["st"], headline["true_res"], headline["parallelism"]
     n_coll = s.get_option("collectives_enqueued")
 
@@ -429,6 +545,7 @@ def main():
     # the opt-in symmetric product on the same system, then configs[1] (N=32768) and the sizes the reference
     # published numbers for (TESTS/BEST_RESULTS:362-372), largest first so the matrix allocation is re-used.
     also, sym = None, None
+    keep_alive = []
     if solo and not args.no_also and not profiled and not args.symmetric:
         try:
             st_s, dt_s = run_config(s, n, args.warmup, args.steps, barrier, symmetric=True, generate=False)
@@ -449,8 +566,6 @@ def main():
                              "kernel": s.gemv_kernel_name()})
             except Exception as e:   # noqa: BLE001
                 sys.stderr.write(f"[bench] side run N={n_also} failed: {e}\n")
-    s.close()
-
     # BASELINE configs[3]: N=131072 in fp32 and in bf16 storage (fp32 accumulate), GEMV only -- the production VALU
     # kernel of each dtype and, for bf16, the MFMA-fed variant beside it (kept as an option: it is slower).  Own
     # contexts, after the fp64 context has been closed; yardstick is still HBM GB/s (GEMV has no contraction for MFMA).
@@ -458,23 +573,34 @@ def main():
     if solo and not args.no_also and not profiled and not args.symmetric:
         config4 = []
         n4 = args.config4_n
+        # NO context is closed before the last timed region: the driver wipes released VRAM in the background, and a
+        # GEMV that runs next to a 69 GB wipe measures 3 % low (round 3's bf16 figure, 0.842, was exactly that: it followed
+        # the close of the fp32 context; profiles/r04_bf16_gap_probe.txt).  fp64 + fp32 + bf16 = 137 GB of 288 GB.
         for dname, dt4, es4, variants in (("f32", lam.F32, 4, ((-1, "VALU (production)"),)),
-                                          ("bf16", lam.BF16, 2, ((-1, "VALU (production)"), (21, "MFMA v_mfma_f32_32x32x16_bf16, p as 3 bf16 terms"),
-                                                                 (20, "MFMA, p rounded to bf16")))):
+                                          ("bf16", lam.BF16, 2, ((-1, "VALU (production)"),) + MFMA_VARIANTS)):
             try:
-                with lam.Solver(dt4) as s4:
-                    s4.generate_random_spd(n4, 1234, 1e4)
-                    s4.generate_random_rhs(1235)
-                    s4.cg_init()                              # p = b: a real vector in the GEMV's p replica
-                    clock_ramp(s4, 0.3)
-                    for v4, what4 in variants:
+                s4 = lam.Solver(dt4)
+                keep_alive.append(s4)
+                s4.generate_random_spd(n4, 1234, 1e4)
+                s4.generate_random_rhs(1235)
+                s4.cg_init()                              # p = b: a real vector in the GEMV's p replica
+                settle(s4, 0.3)
+                for v4, what4 in variants:
+                    try:
                         s4.set_option("gemv_variant", v4)
-                        ts = sorted(s4.gemv_only(10) for _ in range(3))
-                        gb = (es4 * float(n4) * n4 + 4.0 * 2 * n4) / 1e9
-                        config4.append({"n": n4, "dtype": dname, "path": what4, "kernel": s4.gemv_kernel_name(), "gemv_ms": ts[1] * 1e3,
-                                        "gemv_gbps": gb / ts[1], "roofline_frac": gb / ts[1] / HBM_PEAK_GBPS, "algorithmic_bytes": gb * 1e9})
+                    except Exception:   # noqa: BLE001  (the MFMA shapes live in the tuning build: mfma_child below)
+                        continue
+                    ts = sorted(s4.gemv_only(10) for _ in range(5))
+                    gb = (es4 * float(n4) * n4 + 4.0 * 2 * n4) / 1e9
+                    config4.append({"n": n4, "dtype": dname, "path": what4, "kernel": s4.gemv_kernel_name(), "gemv_ms": ts[2] * 1e3,
+                                    "gemv_gbps": gb / ts[2], "roofline_frac": gb / ts[2] / HBM_PEAK_GBPS, "algorithmic_bytes": gb * 1e9})
             except Exception as e:   # noqa: BLE001
                 sys.stderr.write(f"[bench] configs[3] run ({dname}) failed: {e}\n")
+        if mfma_rows:
+            config4.extend(mfma_rows)
+    for ctx in keep_alive:
+        ctx.close()
+    s.close()
 
     ms_per_step = dt / args.steps * 1e3
     gemv_bytes = st["gemv_bytes"]                 # algorithmic bytes of ONE launch on one GPU
@@ -494,15 +620,18 @@ def main():
         "config": {"workload": f"dense SPD CG, N={n} fp64 (BASELINE configs[2]), device-generated random "
                                f"SPD matrix (cond 1e6) + random rhs, {args.steps} fixed iterations",
                    "n": n, "parallelism": parallelism,
-                   "untimed_setup": f"matrix generated on the device; {args.ramp} s of GEMV launches before the warm-up steps "
-                                    "(device clock ramp, profiles/r03_clock_ramp.txt)",
+                   "untimed_setup": f"matrix generated on the device; {args.ramp} s of GEMV launches before the warm-up steps (waits out "
+                                    "the driver's background wipe of the VRAM the child processes released: profiles/r04_bf16_gap_probe.txt; "
+                                    "`value_cold` is the same measurement without it -- rounds 1-2 and BASELINE-style figures are cold)",
                    "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
         "gemv_ms": st["t_gemv"] * 1e3,
+        **({"exchange_effective": effective_exchange} if effective_exchange is not None else {}),
         "other_us": (ms_per_step - st["t_gemv"] * 1e3) * 1e3,
+        "host_enqueue_us_per_step": host_us_per_step,
         "gemv_gbps_per_gpu": achieved,
         "gemv_gbps_aggregate": achieved * n_gpus,
         "rel_residual_recursive": st["rel_err"], "rel_residual_true": true_res, "rccl_init_s": st.get("t_comm_init", 0.0),
-        **({"cold_start": cold_start} if cold_start else {}),
+        **({"cold_start": cold_start, "value_cold": cold_start["value"]} if cold_start else {}),
         "self_check": check, **({"error": "; ".join(failures), "value_unchecked": args.steps / dt} if failures else {}),
         **({"exchange_modes": exchange_modes} if exchange_modes else {}),
         "roofline": {"bound": "hbm", "kernel": kernel_name,

@@ -204,7 +204,7 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
 
 /* ---- options --------------------------------------------------------------------------------- */
 /* name/value pairs; unknown names -> LAM_HIP_EINVAL.
- *   "exchange"      rank mode only.  0 (default): per iteration an 8-byte-per-rank ncclAllGather for p.Ap and for
+ *   "exchange"      RANK MODE (lam_hip_create_rank).  0 (default): per iteration an 8-byte-per-rank ncclAllGather for p.Ap and for
  *                   r.r (summed in rank order by the consumer kernel: deterministic, identical on every rank) and
  *                   ncclAllGather(p slices) -- sliced x, r, Ap, replicated p.  1: ONE ncclAllGather of
  *                   [Ap slice | p.Ap partial] per iteration, r and p kept full-length on every rank and
@@ -220,13 +220,23 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   iteration; consumers poll the tags (bounded).  Results are bit-identical to exchange 0.
  *                   Falls back to 0 when a mapping cannot be made (all ranks agree).  Re-run cg_init/solve
  *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts.
- *                   ONE PROCESS WITH SEVERAL SHARDS (lam_hip_create): 0 (default) orders the shards' streams with
- *                   events (HIP's own guarantees; ~0.25-0.6 ms of host time per iteration at 8 shards); 2 uses the
- *                   same in-kernel flag exchange between the local shards -- no event, no stream wait, 2 launches per
- *                   shard with "overlap" 0: 0.05 ms of host time per iteration at 8 shards, same bits as 0
- *                   (profiles/r03_host_enqueue_cost.txt).  Needs every shard on a device of its own (kernels of one
- *                   shard wait for kernels of the others); shards sharing a device get it only with
- *                   LAM_HIP_DIRECT_SAME_DEVICE=1 and one hardware queue per stream (tests), else 0 is used.
+ *                   ONE PROCESS WITH SEVERAL SHARDS (lam_hip_create): 1 (DEFAULT) = gather-Ap: every shard's GEMV stores its Ap
+ *                   slice and its p.Ap partial straight into every shard's gather buffer (peer stores over xGMI), ONE event
+ *                   join per iteration, r and p full-length on every shard and updated redundantly -- the layout of the
+ *                   reference CPU path (CPU_MPI_OMP.hpp:476,505) and the gather of the single-process CUDA class
+ *                   (GPU/local/ConjugateGradient_MultiGPUS_CUDA.cu:362-376); bit-identical to the rank mode's exchange 1.
+ *                   Needs N % shards == 0, otherwise 0 is used.  0 = sliced vectors and three event joins per iteration
+ *                   (p.Ap partials, r.r partials, p slices).  Both are ordered by HIP events only (system-scope release /
+ *                   acquire at the event): host time to enqueue one iteration at 8 shards 0.15 ms (1) against 0.59 ms (0),
+ *                   profiles/r04_host_enqueue_cost.txt.  2 (EXPERIMENTAL) uses the in-kernel flag exchange between the local
+ *                   shards -- no event, no stream wait, 2 launches per shard with "overlap" 0: 0.05 ms, same bits as 0.
+ *                   Needs every shard on a device of its own (kernels of one shard wait for kernels of the others); shards
+ *                   sharing a device get it only with LAM_HIP_DIRECT_SAME_DEVICE=1 and one hardware queue per stream
+ *                   (tests), else 0 is used.
+ *   "exchange_join" one process, exchange 1: 1 (default with more than two shards) = the iteration's join goes through shard
+ *                   0's stream: it waits for the other shards' posts and records ONE join event they wait for -- 2(P-1)+1
+ *                   runtime calls, two event hops on the device; 0 = every stream waits for every other one -- P(P-1) calls,
+ *                   one hop.  Same bits.
  *   "symmetric"     single shard, fp64/fp32, N a multiple of 4096 (fp64) / 8192 (fp32): 1 = the matrix-vector
  *                   product reads only the upper triangle (A must equal its transpose, which CG requires
  *                   anyway; lam_hip_check_symmetry verifies it) -- about half the HBM traffic per iteration.

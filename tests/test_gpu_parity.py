@@ -625,6 +625,7 @@ def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
         with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
             s.generate_random_spd(n, 7, 200.0)
             s.generate_random_rhs(8)
+            s.set_option("exchange", 0)                 # the three-join exchange these options belong to
             s.set_option("host_threads", threads)
             s.set_option("exchange_hub", hub)
             s.solve(500, 1e-9)

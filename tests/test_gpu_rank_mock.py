@@ -362,3 +362,33 @@ def test_bench_stdout_is_one_json_line_with_real_rccl(tmp_path):
     assert set(out["exchange_modes"]) >= {"allgather_x2+allgather_p", "allgather_Ap", "direct_mailboxes"}
     vals = [m["rel_residual_true"] for m in out["exchange_modes"].values() if "rel_residual_true" in m]
     assert all(abs(v / vals[0] - 1) < 1e-6 for v in vals)
+
+
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_one_process_topology_records_every_exchange(tmp_path, gpus):
+    """`python bench.py --gpus N` WITHOUT a launcher: one process drives N shards (the reference's single-process multi-GPU
+    class, GPU/local/ConjugateGradient_MultiGPUS_CUDA.cu:326-409).  The line carries every exchange of that topology under
+    exchange_modes -- gather-Ap with both joins, the three-join event exchange, the in-kernel flag exchange with and
+    without the own-slice panel -- each with its residual check against the one-GPU solve and the host time per step;
+    the headline is the library default (gather-Ap).  All shards on GPU 0 here (LAM_BENCH_DEVICE_IDS), one hardware
+    queue per stream so that kernels of one shard can wait for kernels of another."""
+    env = dict(os.environ, LAM_BENCH_DEVICE_IDS=",".join(["0"] * gpus), GPU_MAX_HW_QUEUES=str(2 * gpus + 4), LAM_HIP_DIRECT_SAME_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LD_PRELOAD"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "3", "--order", "8192"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == gpus and out["value"] > 0 and out["self_check"]["passed"] and out["self_check"]["vs_one_gpu"] < 1e-9
+    assert out["exchange_effective"] == 1
+    modes = {k: v for k, v in out["exchange_modes"].items() if k != "default"}
+    assert len(modes) == 5, list(modes)
+    assert out["exchange_modes"]["default"].startswith("gather_Ap") and out["value"] == modes[out["exchange_modes"]["default"]]["value"]
+    for name, m in modes.items():
+        assert "error" not in m and m["value"] > 0, (name, m)
+        assert m["vs_one_gpu"] < 1e-9 and abs(m["rel_residual_true"] / m["rel_residual_recursive"] - 1) < 1e-6, (name, m)
+    hosts = {k: v["host_enqueue_us_per_step"] for k, v in modes.items() if "host_enqueue_us_per_step" in v}
+    assert len(hosts) == 5 and all(0 < h < 2000 for h in hosts.values()), hosts
+    assert "1 process" in out["config"]["parallelism"]
