@@ -7,6 +7,6 @@ gfx950 GPU, every compute call raises.
 """
 from ._capi import (  # noqa: F401
     LamHipError, Stats, Solver, build, lib, lib_path, device_count, get_unique_id, partition, rccl_version,
-    F64, F32, BF16,
+    F64, F32, BF16, TUNING_LIB,
 )
 from ._rendezvous import Rendezvous, launched_with_ranks  # noqa: F401,E402

@@ -324,18 +324,18 @@ struct Impl {
 
     // GEMV shapes.  Variants 0-8: gemv_tile_kernel {rows per wave, p-tile columns, p in LDS, rotated
     // tile order}; 9-18: gemv_coop_kernel {rows per workgroup, tile, waves}; 19-22: the MFMA experiment (bf16).
-    // The PRODUCT library holds the shapes that are some dtype's default or part of a reported comparison:
-    // 10 (cooperative rows, 2 rows per 4-wave workgroup: fp64/fp32 production, fastest at N=65536 and N=32768,
-    // profiles/r01_gemv_variant_sweep.txt), 0 (4 rows per wave: bf16 production), 21 / 20 (MFMA-fed bf16, p exact /
-    // p rounded: BASELINE configs[3]'s comparison).  The other 19 are tuning scaffolding and exist only in the
-    // library built with -DLAM_TUNING_VARIANTS (`make tuning` -> liblam_hip_tuning.so, used by tools/gemv_probe.py).
+    // The PRODUCT library holds the shapes that are some dtype's default: 10 (cooperative rows, 2 rows per 4-wave
+    // workgroup: fp64/fp32 production, fastest at N=65536 and N=32768, profiles/r01_gemv_variant_sweep.txt) and 0 (4 rows
+    // per wave: bf16 production).  Everything else -- the other tile / cooperative shapes, the grouped probe and the
+    // MFMA-fed bf16 GEMV of BASELINE configs[3]'s comparison (slower than the VALU kernel) -- exists only in the library
+    // built with -DLAM_TUNING_VARIANTS (`make tuning` -> liblam_hip_tuning.so; tools/gemv_probe.py, bench.py's MFMA child).
     static constexpr int kNumVariants = 25;      // 23, 24: tuning probes gemv_coop_group_kernel (2 / 4 row pairs per workgroup)
     static bool variant_available(int v)
     {
 #ifdef LAM_TUNING_VARIANTS
         return v >= 0 && v < kNumVariants;
 #else
-        return v == 0 || v == 10 || v == 20 || v == 21;
+        return v == 0 || v == 10;
 #endif
     }
     // rows per WORKGROUP of each variant (variants 9.. are the cooperative-row shape: R rows per workgroup)
@@ -506,21 +506,18 @@ struct Impl {
             case 18: launch_coop<3>(c, grid, s.stream, a); break;
             case 23: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 2>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
             case 24: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
-#endif
             case 19: case 20: case 21: case 22:
                 if constexpr (sizeof(TA) == 2) {
                     const int v = variant(c);
                     if (v == 20) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 1>), dim3(grid), dim3(kBlock), 0, s.stream, a);
                     else if (v == 21) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<4, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
-#ifdef LAM_TUNING_VARIANTS
                     else if (v == 19) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<2, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
-                    else if (v == 22) hipLaunchKernelGGL((gemv_mfma_bf16_kernel<1, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
-#endif
-                    else return fail(c, LAM_HIP_EINVAL, "gemv_variant %d is not in this build", v);
+                    else hipLaunchKernelGGL((gemv_mfma_bf16_kernel<1, 4096, true, 3>), dim3(grid), dim3(kBlock), 0, s.stream, a);
                 } else {
                     return fail(c, LAM_HIP_EINVAL, "gemv_variant 19-22 (MFMA) exist for LAM_HIP_BF16 only");
                 }
                 break;
+#endif
             }
         } else {
             hipLaunchKernelGGL((gemv_generic_kernel<TA, TV>), dim3(grid), dim3(kBlock), 0, s.stream, a);
@@ -779,7 +776,11 @@ int reduce_post(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, b
 }
 
 // Is the all-to-all ordering between the shards' streams done through the hub?
+#ifdef LAM_TUNING_VARIANTS
 bool hub_active(const lam_hip_ctx *c) { return !c->rank_mode && c->total_shards > 2 && c->opt_hub != 0 && c->hub_stream != nullptr; }
+#else
+constexpr bool hub_active(const lam_hip_ctx *) { return false; }     // tuning build only (measured slower in wall time)
+#endif
 
 // One process, several shards: after every shard has posted exchange `which` (0 = p.Ap partials, 1 = r.r partials,
 // 2 = p slices), the hub stream waits for the P posts and records ONE join event; every shard then waits for that
@@ -1400,6 +1401,8 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
     });
 }
 
+#ifdef LAM_TUNING_VARIANTS
+// ---- TUNING BUILD ONLY: the whole-iteration persistent launch (experiment; measured 0.7-2 % slower than the two-launch chain)
 constexpr int kPersistLinesMax = 2048;      // >= the most worker workgroups a device can hold (8 x 256 CUs)
 
 // Can the current CG state run on the whole-iteration persistent launch, and with how many workers?  One shard, fp64 /
@@ -1478,6 +1481,9 @@ int enqueue_persist_chunk(lam_hip_ctx *c, int k_first, int count, double rel_err
         }
     });
 }
+#else
+int decide_persistent(lam_hip_ctx *c) { c->persist_active = false; return 0; }
+#endif  // LAM_TUNING_VARIANTS
 
 int do_cg_init(lam_hip_ctx *c)
 {
@@ -1687,6 +1693,8 @@ int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
     }
 }
 
+#ifdef LAM_TUNING_VARIANTS
+// TUNING BUILD ONLY (option "host_threads").
 // Host barrier of the per-shard enqueue threads.  wait(flags) returns the OR of the flags every thread brought to
 // THIS barrier, so all threads leave the loop at the same barrier (a flag raised between two barriers is seen by
 // everybody at the next one, by nobody before).
@@ -1712,6 +1720,7 @@ struct HostBarrier {
         return result[(g + 1) & 1];
     }
 };
+#endif
 
 }  // namespace
 
@@ -2165,6 +2174,9 @@ static int lag_check(lam_hip_ctx *c, ShardBase &s0, int k)
     return (pr.stop_at != 0 && (pr.stop_at <= k - kLag || level_stop)) ? 1 : 0;
 }
 
+#ifdef LAM_TUNING_VARIANTS
+// TUNING BUILD ONLY (option "host_threads": 0.30 ms of host time per iteration at 8 shards where the plain loop takes 0.59 and the
+// gather-Ap exchange 0.15 -- the runtime serialises much of it).
 // One process, several shards: every shard is enqueued by a host thread of its own (the reference drives each device
 // from its own OpenMP thread, ConjugateGradient_MultiGPUS_CUDA.cu:264-283,337-378).  With one thread for P shards an
 // iteration costs the host 3P launches + ~3P event records + 3P(P-1) stream waits one after the other; here they are
@@ -2233,6 +2245,7 @@ static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_e
         if (rcs[q] != 0) return rcs[q];
     return 0;
 }
+#endif  // LAM_TUNING_VARIANTS
 
 int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stats *st)
 {
@@ -2251,10 +2264,11 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     const bool stopped = s0.sc_host->stop != 0;
     const int k_first = c->k_done + 1;
     for (int i = 0; i < kLag; i++) s0.timed_slot[i] = false;
-    const bool threaded = !c->rank_mode && c->total_shards > 1 && c->opt_host_threads != 0 && !c->cg_direct && !c->cg_exchange1;
     if (stopped) {
         // nothing to enqueue
-    } else if (c->persist_active) {
+    }
+#ifdef LAM_TUNING_VARIANTS
+    else if (c->persist_active) {
         // whole-iteration launches of `chunk` iterations; at most two of them are in the queue (the host waits for the
         // last iteration of the launch before the previous one to report).  After a stop the queued launch returns at once.
         const int chunk = (int)std::max<int64_t>(1, c->opt_persist_chunk);
@@ -2274,10 +2288,12 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             prev_last = k_first + done - 1;
             enq += cnt;
         }
-    } else if (threaded) {
+    } else if (!c->rank_mode && c->total_shards > 1 && c->opt_host_threads != 0 && !c->cg_direct && !c->cg_exchange1) {
         LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &gemv_ms, &gemv_samples));
         c->gather_pending = false;
-    } else {
+    }
+#endif
+    else {
         for (int i = 0; i < iters; i++) {
             const int k = k_first + i;
             const int slot = i % kLag;
@@ -2323,6 +2339,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         st->t_total = t1 - t0;
         st->t_iter = ran > 0 ? (t1 - t0) / ran : 0.0;
         st->t_gemv = gemv_samples > 0 ? gemv_ms * 1e-3 / gemv_samples : 0.0;
+#ifdef LAM_TUNING_VARIANTS
         if (c->persist_active && c->persist_ticks != nullptr) {
             // the persistent launch times its GEMV phases itself (constant-rate 100 MHz counter, reducer workgroup):
             // from the previous hand-over to the moment the last partial of p.Ap has been summed
@@ -2332,6 +2349,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             const unsigned long long dt = c->persist_ticks_host[0] - before[0], dn = c->persist_ticks_host[1] - before[1];
             st->t_gemv = dn > 0 ? (double)dt * 1e-8 / (double)dn : 0.0;
         }
+#endif
         st->t_comm_init = c->t_comm_init;
         st->gemv_bytes = (double)c->esz_a() * (double)s0.nrows * (double)c->n + (double)c->esz_v() * (double)(c->n + s0.nrows);
     }
@@ -2704,6 +2722,14 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *c, char *buf, size_t len)
     return 0;
 }
 
+#ifdef LAM_TUNING_VARIANTS
+static constexpr bool kTuningBuild = true;
+#else
+static constexpr bool kTuningBuild = false;
+#endif
+static const char *const kTuningOnly = "%s is an experiment that did not win: it exists in the tuning build only (`make tuning`, load "
+                                       "liblam_hip_tuning.so through LAM_HIP_LIB), not in the product library";
+
 int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
 {
     if (!c || !name) return LAM_HIP_EINVAL;
@@ -2719,17 +2745,26 @@ int lam_hip_set_option(lam_hip_ctx *c, const char *name, int64_t value)
     else if (!strcmp(name, "overlap")) c->opt_overlap = value;
     else if (!strcmp(name, "exchange")) { c->opt_exchange = value; c->cg_ready = false; }
     else if (!strcmp(name, "exchange_join")) c->opt_join = value;
-    else if (!strcmp(name, "finalize")) { c->opt_finalize = value; c->cg_ready = false; }
+    else if (!strcmp(name, "finalize")) {
+        if (value == 0 && !kTuningBuild) return fail(c, LAM_HIP_EINVAL, kTuningOnly, "finalize = 0 (separate reduction launches, the round-1 chain)");
+        c->opt_finalize = value; c->cg_ready = false;
+    }
     else if (!strcmp(name, "upload_staging")) c->opt_upload_staging = value;
     else if (!strcmp(name, "reuse_matrix")) c->opt_reuse_matrix = value;
     else if (!strcmp(name, "fuse_update")) { c->opt_fuse = value; c->cg_ready = false; }
-    else if (!strcmp(name, "persistent")) { c->opt_persistent = value; c->cg_ready = false; }
-    else if (!strcmp(name, "persist_chunk")) c->opt_persist_chunk = value;
+    else if (!strcmp(name, "persistent") || !strcmp(name, "persist_chunk")) {
+        if (!kTuningBuild && !(value == 0 && !strcmp(name, "persistent"))) return fail(c, LAM_HIP_EINVAL, kTuningOnly, "the whole-iteration persistent launch");
+        if (!strcmp(name, "persistent")) { c->opt_persistent = value; c->cg_ready = false; }
+        else c->opt_persist_chunk = value;
+    }
     else if (!strcmp(name, "symmetric")) { c->opt_symmetric = value; c->cg_ready = false; }   // other kernels, other partial arrays
     else if (!strcmp(name, "gemv_timing")) c->opt_gemv_timing = value < 0 ? 0 : value;
     else if (!strcmp(name, "verify_direct")) c->opt_verify_direct = value;
-    else if (!strcmp(name, "host_threads")) c->opt_host_threads = value;
-    else if (!strcmp(name, "exchange_hub")) c->opt_hub = value;
+    else if (!strcmp(name, "host_threads") || !strcmp(name, "exchange_hub")) {
+        if (value != 0 && !kTuningBuild) return fail(c, LAM_HIP_EINVAL, kTuningOnly, name);
+        if (!strcmp(name, "host_threads")) c->opt_host_threads = value;
+        else c->opt_hub = value;
+    }
     else if (!strcmp(name, "assume_cus")) { c->opt_assume_cus = value; c->cg_ready = false; }
     else if (!strcmp(name, "panel_lo")) c->opt_panel_lo = value;
     else if (!strcmp(name, "panel_hi")) c->opt_panel_hi = value;

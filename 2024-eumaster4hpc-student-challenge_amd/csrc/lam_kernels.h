@@ -721,6 +721,10 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     }
 }
 
+// ==== From here to the matching #endif: TUNING BUILD ONLY (-DLAM_TUNING_VARIANTS, `make tuning` -> liblam_hip_tuning.so).
+// Experiments that were built, tested, measured and did not win: the grouped cooperative-row
+// probe, the MFMA-fed bf16 GEMV.  The product library does not carry them.
+#ifdef LAM_TUNING_VARIANTS
 // One p tile's worth of the cooperative-row stream as a function: R rows, columns [c0, c0 + cols) of each, accumulated
 // into acc[R] -- statement for statement the tile body of gemv_coop_kernel (which keeps its own inline copy: moving it
 // behind this call changed the production kernels' register allocation), so that cg_persist_kernel adds a row's
@@ -775,8 +779,7 @@ __device__ __forceinline__ void coop_stream_tile(const TA *const (&rowp)[R], uin
     }
 }
 
-#ifdef LAM_TUNING_VARIANTS
-// Tuning probe (not in the product library): the cooperative-row GEMV with GROUP consecutive row pairs per workgroup that
+// Tuning probe: the cooperative-row GEMV with GROUP consecutive row pairs per workgroup that
 // share every staged p tile -- does halving / quartering the number of workgroups (launches, epilogues, staged tiles) lift
 // the short-row sizes?  Same per-row arithmetic; the rotated tile order starts at blockIdx (not pair index) % tiles, so the
 // bits differ from the production kernel's.
@@ -861,7 +864,6 @@ gemv_coop_group_kernel(GemvArgs<TA, TV> a)
         publish_partial(t, a.partial, a.fin);
     }
 }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // MFMA experiment for the bf16-storage GEMV (BASELINE configs[3]): can the matrix cores take the
@@ -1007,6 +1009,8 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
         publish_partial(t, a.partial, a.fin);
     }
 }
+
+#endif  // LAM_TUNING_VARIANTS (grouped cooperative rows, MFMA-fed bf16 GEMV)
 
 // ---------------------------------------------------------------------------------------------
 // Symmetric product (option "symmetric", single shard): y = A p reading only the UPPER triangle.
@@ -1586,7 +1590,9 @@ update_p_full_kernel(const double *__restrict__ red, int nred, CgScalars *sc, in
         p_full[i] = r_full[i] + beta * p_full[i];
 }
 
+#ifdef LAM_TUNING_VARIANTS
 // ---------------------------------------------------------------------------------------------
+// TUNING BUILD ONLY.
 // Whole-iteration persistent launch (option "persistent"; one shard, fp64 / fp32, N a multiple of the vector width).
 // EXPERIMENT, off by default; DESIGN.md section 6 has the measurement.
 //
@@ -1903,6 +1909,7 @@ cg_persist_kernel(PersistArgs<TA, TV> a)
             a.pbuf[0][i] = ld_agent(a.r + i) + beta * ld_agent(pold + i);
     }
 }
+#endif  // LAM_TUNING_VARIANTS (persistent launch)
 
 // standalone BLAS-1 pieces (lam_hip_dot / lam_hip_axpby and the residual check)
 template <typename TV>

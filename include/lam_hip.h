@@ -244,14 +244,18 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   whether the current context can use it.
  *   "finalize"      several shards: 1 (default) = the last workgroup of the GEMV / update kernel reduces the
  *                   shard's partial dot product inside the launch (3 launches per iteration for any shard
- *                   count); 0 = separate 1-workgroup reduction launches (5 per iteration; A/B measurements).
+ *                   count); 0 = separate 1-workgroup reduction launches (5 per iteration; the round-1 chain, kept for A/B
+ *                   measurements: TUNING BUILD ONLY, the product library refuses it).
  *   "fuse_update"   one shard, and exchange 2: 1 (default) = the x, r and p updates of an iteration are ONE launch (the
  *                   r.r total is handed over inside the launch); with exchange 2 and overlap 0 that launch also waits
  *                   for the peers' p slices, so an iteration is two launches.  0 = two kernels.  Same bits either way.
  *                   The fused launch's workgroups wait for each other, so it is used only when cg_init finds that
  *                   the whole grid can be resident at once (occupancy x CU count; "fuse_effective" tells,
  *                   "assume_cus" overrides the CU count for tests); otherwise the two-kernel form runs.
- *   "persistent"    one shard, fp64/fp32, even N a multiple of the 16-byte vector width: 1 = EXPERIMENT, whole CG
+ *   The options marked TUNING BUILD ONLY are experiments that were built, tested, measured and did not win.  They exist in
+ *   liblam_hip_tuning.so (`make tuning`, same ABI; tools and tests load it through the environment variable LAM_HIP_LIB);
+ *   the product library refuses to switch them on (LAM_HIP_EINVAL) and accepts switching them off.
+ *   "persistent"    TUNING BUILD ONLY.  one shard, fp64/fp32, even N a multiple of the 16-byte vector width: 1 = EXPERIMENT, whole CG
  *                   iterations inside one launch ("persist_chunk", default 32, iterations per launch): resident GEMV
  *                   workers + one reducer workgroup, two in-launch hand-overs per iteration, same bits as the
  *                   two-launch chain; measured 0.7-2 % SLOWER (profiles/r03_persistent_vs_two_launch.txt), so 0 is the
@@ -261,9 +265,9 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   their average); 1 = every iteration (costs ~8 us per iteration: each record is a marker packet
  *                   between the kernels), 0 = never (t_gemv = 0).  The host follows the iteration through a progress
  *                   word in pinned memory, not through events.
- *   "host_threads"  one process, several shards: 1 = every shard is enqueued by a host thread of its own (the
+ *   "host_threads"  TUNING BUILD ONLY.  one process, several shards, exchange 0: 1 = every shard is enqueued by a host thread of its own (the
  *                   reference's OpenMP-thread-per-device shape); 0 (default) = one thread enqueues all shards.
- *   "exchange_hub"  one process, more than two shards: 1 = the shards' streams meet at one join event per exchange
+ *   "exchange_hub"  TUNING BUILD ONLY.  one process, more than two shards, exchange 0: 1 = the shards' streams meet at one join event per exchange
  *                   (2P+1 runtime calls) instead of every stream waiting for every other one (P(P-1)); 0 (default).
  *                   Measured host cost of both: profiles/r03_host_enqueue_cost.txt.  Same bits in every combination.
  *   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "host_enqueue_ns" (get only): runtime calls issued and host
@@ -277,11 +281,12 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.  Exchange 2: 1 runs
  *                   that own-columns panel in front of the wait for the peers' p slices; 0 waits first and
  *                   launches the GEMV once.
- *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype (10 for fp64/fp32, 0 for bf16); 20 / 21 = the
- *                   MFMA-fed bf16 GEMV (p rounded to bf16 / p exact as three bf16 terms; LAM_HIP_BF16 only; BASELINE
- *                   configs[3]'s comparison, slower than the VALU kernel).  The other shapes (1-9, 11-19, 22) are tuning
- *                   scaffolding: they exist only in the tuning build (`make tuning`, liblam_hip_tuning.so, used by
- *                   tools/gemv_probe.py; "tuning_variants" tells) and are refused with LAM_HIP_EINVAL here.
+ *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype (10 for fp64/fp32, 0 for bf16).  Every other shape
+ *                   is TUNING BUILD ONLY ("tuning_variants" tells which build this is) and refused with LAM_HIP_EINVAL by the
+ *                   product library: 1-9, 11-18, 23, 24 tile / cooperative-row shapes (tools/gemv_probe.py), 19-22 the MFMA-fed
+ *                   bf16 GEMV (20: p rounded to bf16, 21: p exact as three bf16 terms; LAM_HIP_BF16 only) -- BASELINE
+ *                   configs[3]'s comparison, measured slower than the VALU kernel (bench.py measures it in a child process
+ *                   on the tuning build).
  *   "nt_loads"      1 (default) = non-temporal loads for the matrix stream.
  *   "force_generic" 1 = always use the any-N scalar-load GEMV.
  *   "probe_rows"    lam_hip_gemv_only: use only the first ROWS rows of a shard (a P-way split's shape).

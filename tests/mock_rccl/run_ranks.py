@@ -56,7 +56,8 @@ def main():
                 setup(s)
                 s.set_option("overlap", a.overlap)
                 s.set_option("exchange", a.exchange)
-                s.set_option("finalize", a.finalize)
+                if a.finalize != 1:
+                    s.set_option("finalize", a.finalize)     # 0 exists in the tuning build only
                 s.set_option("fuse_update", a.fuse)
                 if a.chunk > 0:
                     s.cg_init()

@@ -32,6 +32,17 @@ def _rand_matrix(n, m, seed):
     return rng.uniform(-1.0, 1.0, size=(n, m))
 
 
+def _tuning_case(lam, name, *args, timeout=600):
+    """Run one case of tests/tuning_cases.py in a child process on the TUNING build of the library (the experiments that did
+    not win -- MFMA-fed GEMV, separate reduction launches, enqueue threads, hub, persistent launch -- are not in the product)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_cases.py")
+    r = subprocess.run([sys.executable, script, name, *map(str, args)], env=dict(os.environ, LAM_HIP_LIB=lam.TUNING_LIB),
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok " + name), r.stdout[-2000:] + r.stderr[-3000:]
+
+
 # ------------------------------------------------------------------------------------------------
 # single operators
 # ------------------------------------------------------------------------------------------------
@@ -359,24 +370,12 @@ def test_cg_with_split_gemv_matches_unsplit(lam, oracle, n, lo, hi, generic):
 # ------------------------------------------------------------------------------------------------
 # MFMA experiment kernels for bf16 storage (gemv_variant 19-22): same answers as the VALU kernel
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant,tol", [(21, 32 * 2.0 ** -24), (20, 2.0 ** -8)])
+@pytest.mark.parametrize("variant", [21, 20])
 @pytest.mark.parametrize("n", [512, 4096, 4104, 9000])
-def test_mfma_bf16_gemv_matches_fp64(lam, variant, tol, n):
-    """Asymmetric random data, so a wrong fragment/diagonal map cannot cancel.  Variant 21 feeds
-    p as three exact bf16 terms (fp32-faithful); variant 20 rounds p to bf16 (8 significant bits).  (The two
-    other MFMA shapes, 19 and 22, are tuning shapes: test_tuning_build_variants.)"""
-    A = _rand_matrix(n, n, n + 3).astype(np.float32)
-    x = np.random.default_rng(n + 4).uniform(-1, 1, n).astype(np.float32)
-    with lam.Solver(lam.BF16) as s:
-        s.set_matrix(A)
-        A_dev = s.download_rows(0, n).astype(np.float64)
-        y_valu = s.gemv(x)
-        s.set_option("gemv_variant", variant)
-        y = s.gemv(x)
-    y64 = A_dev @ x.astype(np.float64)
-    scale = np.abs(A_dev) @ np.abs(x.astype(np.float64))
-    assert np.max(np.abs(y.astype(np.float64) - y64) / scale) <= tol
-    assert np.max(np.abs(y_valu.astype(np.float64) - y64) / scale) <= 32 * 2.0 ** -24
+def test_mfma_bf16_gemv_matches_fp64(lam, variant, n):
+    """The MFMA-fed bf16 GEMV (BASELINE configs[3]'s comparison; slower than the VALU kernel, so it lives in the tuning build):
+    variant 21 feeds p as three exact bf16 terms (fp32-faithful), variant 20 rounds p to bf16 -- tests/tuning_cases.py `mfma`."""
+    _tuning_case(lam, "mfma", variant, n)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -567,19 +566,18 @@ def test_symmetric_option_preconditions(lam):
 
 @pytest.mark.parametrize("dtype_name,n,shards", [("F64", 1000, 1), ("F64", 4096, 1), ("F32", 2048, 1), ("F64", 3000, 3)])
 def test_launch_chain_variants_are_bit_identical(lam, dtype_name, n, shards):
-    """The iteration's vector work exists in three launch shapes -- fused update (one launch, the r.r total handed
-    over inside the launch through the context's mailbox), separate update_xr / update_p with the reducer
-    workgroup, and the round-1 chain with separate reduction launches (finalize = 0) -- which must be the same
-    arithmetic: identical iteration counts, residuals and solution bits.  (Several shards in one process always
-    use the two-kernel form; fuse_update is then ignored.)"""
+    """The iteration's vector work exists in two launch shapes in the product -- fused update (one launch, the r.r total handed
+    over inside the launch through the context's mailbox) and separate update_xr / update_p with the reducer workgroup --
+    which must be the same arithmetic: identical iteration counts, residuals and solution bits.  (Several shards in one
+    process always use the two-kernel form; fuse_update is then ignored.)  The round-1 chain with separate reduction launches
+    (finalize = 0) is a tuning-build option and is compared there, on both event-ordered exchanges (tuning_cases.py)."""
     dt = getattr(lam, dtype_name)
     res = []
-    for fuse, fin in ((1, 1), (0, 1), (0, 0)):
+    for fuse in (1, 0):
         with lam.Solver(dt, n_shards=shards, device_ids=[0] * shards) as s:
             s.generate_random_spd(n, 5, 300.0)
             s.generate_random_rhs(6)
             s.set_option("fuse_update", fuse)
-            s.set_option("finalize", fin)
             s.solve(400, 1e-9 if dtype_name == "F64" else 1e-5)
             res.append((s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes(), s.true_residual()))
             # continuing an interrupted solve in chunks gives the same bits as well
@@ -587,7 +585,8 @@ def test_launch_chain_variants_are_bit_identical(lam, dtype_name, n, shards):
             for _ in range(3):
                 s.cg_iterate(7, 0.0)
             res[-1] += (s.solution().tobytes(),)
-    assert res[0] == res[1] == res[2]
+    assert res[0] == res[1]
+    _tuning_case(lam, "launch_chain", dtype_name, n, shards)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -615,27 +614,10 @@ def test_fused_update_needs_a_fully_resident_grid(lam, dtype_name, n):
 
 @pytest.mark.parametrize("shards,n", [(2, 1024), (3, 3000), (8, 4096), (5, 1001)])
 def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
-    """One process, several shards, three ways of ordering the shards' streams from the host: the hub (default: the
-    streams meet at one join event per exchange), the all-to-all stream waits of round 2, and one enqueue thread per
-    shard (the reference's OpenMP-thread-per-device shape, MultiGPUS_CUDA.cu:337-378) -- same kernels, same stream
-    order per shard, same dependencies: identical bits, also when the solve stops early and when it is continued
-    in chunks."""
-    res = []
-    for threads, hub in ((0, 1), (0, 0), (1, 0), (1, 1)):
-        with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
-            s.generate_random_spd(n, 7, 200.0)
-            s.generate_random_rhs(8)
-            s.set_option("exchange", 0)                 # the three-join exchange these options belong to
-            s.set_option("host_threads", threads)
-            s.set_option("exchange_hub", hub)
-            s.solve(500, 1e-9)
-            assert s.stats["converged"]
-            out = (s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes(), s.true_residual())
-            s.cg_init()
-            for chunk in (1, 2, 9, 30):
-                s.cg_iterate(chunk, 0.0)
-            res.append(out + (s.solution().tobytes(), s.stats["rel_err"]))
-    assert res[0] == res[1] == res[2] == res[3]
+    """The three-join event exchange ordered by all-to-all stream waits (product), through a hub stream, and with one enqueue
+    thread per shard (tuning-build experiments: neither reached the host cost of the gather-Ap exchange): same bits --
+    tests/tuning_cases.py `host_enqueue`."""
+    _tuning_case(lam, "host_enqueue", shards, n)
 
 
 @pytest.mark.parametrize("shards,n,dtype_name", [(2, 1024, "F64"), (4, 4096, "F64"), (8, 8192, "F64"), (3, 3000, "F64"), (8, 4104, "F64"),
@@ -735,7 +717,7 @@ def test_changing_the_product_kernel_needs_a_new_cg_init(lam):
         s.generate_random_rhs(6)
         s.cg_init()
         s.cg_iterate(3, 0.0)
-        for opt, val in (("symmetric", 1), ("symmetric", 0), ("fuse_update", 0), ("finalize", 0)):
+        for opt, val in (("symmetric", 1), ("symmetric", 0), ("fuse_update", 0)):
             s.set_option(opt, val)
             with pytest.raises(lam.LamHipError):
                 s.cg_iterate(1, 0.0)
@@ -751,11 +733,17 @@ def test_tuning_build_variants(lam):
     import sys
     with lam.Solver(lam.F64) as s:
         assert s.get_option("tuning_variants") == 0
-        for v in (1, 9, 13, 18, 19, 22):
+        for v in (1, 9, 13, 18, 19, 20, 21, 22, 23):
             with pytest.raises(lam.LamHipError):
                 s.set_option("gemv_variant", v)
         for v in (-1, 0, 10):
             s.set_option("gemv_variant", v)
+        # ... and the other experiments that did not win: not in the product library either
+        for opt, val in (("persistent", 1), ("persist_chunk", 8), ("host_threads", 1), ("exchange_hub", 1), ("finalize", 0)):
+            with pytest.raises(lam.LamHipError, match="tuning build"):
+                s.set_option(opt, val)
+        for opt, val in (("persistent", 0), ("host_threads", 0), ("exchange_hub", 0), ("finalize", 1)):
+            s.set_option(opt, val)                     # switching them OFF is always accepted
     probe = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "gemv_probe.py")
     for dtype, variants in (("f64", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,23,24"), ("f32", "0,8,9,10,12,15,18,23"),
                             ("bf16", "0,1,10,19,20,21,22")):
@@ -856,38 +844,23 @@ def test_soak_in_kernel_handovers_stay_deterministic(lam, n, cycles, shards):
 
 @pytest.mark.parametrize("dtype_name,n", [("F64", 4096), ("F64", 10000), ("F64", 1000), ("F32", 8192), ("F64", 12290)])
 def test_persistent_launch_is_bit_identical_to_the_two_launch_chain(lam, dtype_name, n):
-    """Option "persistent" (experiment): whole iterations inside ONE launch -- persistent GEMV workers, p formed while
-    its tile is staged, two in-launch hand-overs per iteration -- must be the same arithmetic as the two-launch chain:
-    identical iteration counts, residuals and solution bits, whatever the number of iterations per launch (each launch
-    ends by materialising the explicit p the two-launch form keeps) and however the solve is cut into calls."""
-    dt = getattr(lam, dtype_name)
-    tol = 1e-9 if dtype_name == "F64" else 1e-5
-    res = []
-    for persistent, chunk in ((0, 32), (1, 32), (1, 1), (1, 5)):
-        with lam.Solver(dt) as s:
-            s.generate_random_spd(n, 5, 300.0)
-            s.generate_random_rhs(6)
-            s.set_option("persistent", persistent)
-            s.set_option("persist_chunk", chunk)
-            s.solve(400, tol)
-            assert s.get_option("persistent_effective") == persistent
-            assert s.stats["converged"]
-            out = (s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes(), s.true_residual())
-            s.cg_init()
-            for _ in range(3):
-                st = s.cg_iterate(7, 0.0)
-            assert st["t_gemv"] > 0
-            res.append(out + (s.solution().tobytes(), st["rel_err"]))
-    assert res[0] == res[1] == res[2] == res[3]
+    """The whole-iteration persistent launch (tuning-build experiment, measured 0.7-2 % slower than the two-launch chain) is
+    the same arithmetic as the product path: identical bits -- tests/tuning_cases.py `persistent`."""
+    _tuning_case(lam, "persistent", dtype_name, n)
 
 
-def test_fuzz_bit_preserving_options():
-    """tools/fuzz_options.py: 150 random (dtype, N, shards, iterations, call pattern) cases, each solved with the default
-    options and with a random mix of the options that only change HOW an iteration is launched and enqueued (fused /
-    two-kernel vector step, in-kernel / separate reduction, event sampling, enqueue threads, hub, persistent launch and
-    its chunking): every case must give the same bits (round-3 builder run: 800 of 800)."""
+@pytest.mark.parametrize("build", ["product", "tuning"])
+def test_fuzz_bit_preserving_options(lam, build):
+    """tools/fuzz_options.py: random (dtype, N, shards, exchange, iterations, call pattern) cases, each solved with the default
+    options and with a random mix of the options that only change HOW an iteration is launched and enqueued -- product
+    library: fused / two-kernel vector step, event sampling, the join of the gather-Ap exchange; tuning build in addition:
+    separate reduction launches, enqueue threads, hub, persistent launch and its chunking.  Every case must give the same bits."""
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_options.py"), "150", "11"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "150 of 150 cases" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    env = dict(os.environ)
+    if build == "tuning":
+        env["LAM_HIP_LIB"] = lam.TUNING_LIB
+    cases = "120" if build == "product" else "80"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_options.py"), cases, "11"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and f"{cases} of {cases} cases" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -207,9 +207,11 @@ def test_rank_mode_low_precision(mock_async, tmp_path, P, n, mode, dtype, exchan
 def test_finalize_kernel_variant_matches_in_kernel_reduction(mock_async, tmp_path):
     """option finalize=0 (separate 1-block reduction launches, the round-1 chain) and the default in-kernel
     last-arriver reduction give bit-identical solves."""
+    import importlib
+    tuning = importlib.import_module("2024-eumaster4hpc-student-challenge_amd").TUNING_LIB     # finalize = 0 lives in the tuning build
     outs = []
     for fin in (1, 0):
-        r, out, lines = _run(mock_async, tmp_path, 4, 4096, "spd", "--finalize", fin)
+        r, out, lines = _run(mock_async, tmp_path, 4, 4096, "spd", "--finalize", fin, env_extra={"LAM_HIP_LIB": tuning})
         _check_mock_stats(lines, 4)
         os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
         outs.append(out)

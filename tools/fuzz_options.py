@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the launch / enqueue options that must not change a single bit: for random (dtype, N,
-shards, seed) the solve with default options against the solve with a random combination of fuse_update, finalize,
-host_threads, exchange_hub, gemv_timing, persistent / persist_chunk, and the solve cut into random cg_iterate chunks.
-Also compares with the CPU oracle at a tolerance.   usage: fuzz_options.py [cases] [seed]"""
+shards, seed, exchange) the solve with default options against the solve with a random combination of the options
+that only change HOW an iteration is launched and enqueued, and with the solve cut into random cg_iterate chunks.
+Product library: fuse_update, gemv_timing, exchange_join.  Tuning build (LAM_HIP_LIB=.../liblam_hip_tuning.so) adds
+the experiments that live there: finalize, host_threads, exchange_hub, persistent / persist_chunk.
+    usage: fuzz_options.py [cases] [seed]"""
 import importlib
 import os
 import random
@@ -30,6 +32,8 @@ def run(dt, n, shards, seed, opts, chunks):
 
 
 def main():
+    with lam.Solver(lam.F64) as s0:
+        TUNING = s0.get_option("tuning_variants") == 1      # noqa: N806
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     # LAM_HIP_DIRECT_SAME_DEVICE=1 (+ GPU_MAX_HW_QUEUES >= 2 x shards) in the environment: multi-shard cases also try exchange 2
@@ -42,11 +46,15 @@ def main():
         n = max(n, shards)
         total = min(rng.randint(1, 60), max(1, n // 3))      # stay short of exact convergence (r = 0 gives 0/0, as in the reference)
         seed = rng.randint(1, 10 ** 6)
-        ref = run(dt, n, shards, seed, {}, [total])
-        opts = {"fuse_update": rng.choice((0, 1)), "finalize": rng.choice((1, 1, 0)), "gemv_timing": rng.choice((0, 1, 3, 8)),
-                "host_threads": rng.choice((0, 1)), "exchange_hub": rng.choice((0, 1)), "persistent": rng.choice((0, 1)),
-                "persist_chunk": rng.choice((1, 2, 7, 32))}
-        if direct and shards > 1:
+        # the exchange is part of the CASE (gather-Ap sums r.r over full-length partials: other bits than the sliced form)
+        exchange = rng.choice((0, 1)) if shards > 1 else 0
+        base = {"exchange": exchange} if shards > 1 else {}
+        ref = run(dt, n, shards, seed, base, [total])
+        opts = dict(base, fuse_update=rng.choice((0, 1)), gemv_timing=rng.choice((0, 1, 3, 8)), exchange_join=rng.choice((0, 1)))
+        if TUNING:
+            opts.update({"finalize": rng.choice((1, 1, 0)), "host_threads": rng.choice((0, 1)), "exchange_hub": rng.choice((0, 1)),
+                         "persistent": rng.choice((0, 1)), "persist_chunk": rng.choice((1, 2, 7, 32))})
+        if direct and shards > 1 and exchange == 0:
             # the in-kernel flag exchange between the local shards, one GEMV launch per shard (the own-slice panel of
             # overlap = 1 adds a row's products in another order): same bits as the event exchange; needs finalize = 1
             opts.update({"exchange": 2, "overlap": 0, "finalize": 1})

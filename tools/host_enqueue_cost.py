@@ -21,6 +21,8 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 os.environ.setdefault("LAM_HIP_DIRECT_SAME_DEVICE", "1")      # exchange 2 with all shards on one device (one hardware queue per stream above)
 
+# the experiments this tool measures (host_threads / exchange_hub / persistent / finalize = 0) live in the tuning build of the library
+os.environ.setdefault("LAM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2024-eumaster4hpc-student-challenge_amd", "liblam_hip_tuning.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 

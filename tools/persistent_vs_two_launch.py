@@ -8,6 +8,8 @@ import sys
 
 import numpy as np
 
+# the experiments this tool measures (host_threads / exchange_hub / persistent / finalize = 0) live in the tuning build of the library
+os.environ.setdefault("LAM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2024-eumaster4hpc-student-challenge_amd", "liblam_hip_tuning.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 

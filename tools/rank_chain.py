@@ -8,6 +8,8 @@ tools/summarize_chain.py; run it bare for the wall-clock table.
     finalize 1 (3 launches + 3 collectives), exchange 1 with finalize 0 / 1, each with overlap 1 and 0."""
 import importlib, os, sys
 os.environ["LAM_HIP_FORCE_RCCL"] = "1"
+# the experiments this tool measures (host_threads / exchange_hub / persistent / finalize = 0) live in the tuning build of the library
+os.environ.setdefault("LAM_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "2024-eumaster4hpc-student-challenge_amd", "liblam_hip_tuning.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 
