@@ -36,6 +36,7 @@
 #include <vector>
 
 #include <sched.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "../../include/lam_hip.h"
@@ -50,6 +51,13 @@ thread_local std::string g_create_error;
 double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+uint64_t thread_cpu_ns()
+{
+    struct timespec ts;
+    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) != 0) return 0;
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
 constexpr int kLag = 4;          // iterations the host may run ahead of the stop flag
@@ -162,6 +170,10 @@ struct lam_hip_ctx {
     // runtime calls issued by the iteration loop (diagnostics: host cost of an iteration, tools/host_enqueue_cost.py)
     std::atomic<uint64_t> n_launch{0}, n_record{0}, n_wait{0}, n_setdev{0};
     uint64_t enqueue_ns = 0;       // host time spent issuing iterations (the waits for the device's progress excluded)
+    uint64_t host_cpu_ns = 0;      // CPU time (CLOCK_THREAD_CPUTIME_ID) the calling thread spent inside lam_hip_cg_iterate
+    double iter_est_s = 0.0;       // observed seconds per iteration (await_progress sleeps a fraction of it between polls)
+    double prog_t = 0.0;           // when / at which iteration the last awaited progress was seen
+    int prog_iter = 0;
     std::mutex err_mu;             // `err` may be written by the per-shard enqueue threads
     // direct exchange (option exchange = 2): peer-mapped p replicas and mailboxes (lam_kernels.h, Mail)
     Mail *peer_mail[kMaxShards] = {};           // every shard's mailbox as seen from this process (own included)
@@ -174,7 +186,12 @@ struct lam_hip_ctx {
     int64_t opt_verify_direct = 1;              // lam_hip_solve on the direct exchange: compare the recomputed residual with
                                                 // the recursive one afterwards; on a mismatch solve again on the RCCL exchange
     int64_t direct_fallbacks = 0;               // how often that happened
-    uint32_t epoch = 0;                         // bumped by every cg_init: mailbox tags never repeat
+    uint32_t epoch = 0;                         // bumped by every cg_init
+    uint64_t seq_base = 0, seq_span = 1;        // hand-over number of iteration k of the current solve = seq_base + k: grows by one
+                                                // per iteration over the whole life of the context and never restarts (cg_init moves
+                                                // the base past every iteration of the previous solve), so the 32-bit tags of the
+                                                // in-kernel hand-overs (lam_kernels.h, MailSlot) cannot meet a stale equal; the same
+                                                // on every rank (all ranks enqueue the same iterations)
     int *direct_err = nullptr;                  // pinned host: a bounded in-kernel wait expired ([0] = which, see cg_iterate)
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
@@ -628,6 +645,27 @@ void abandon(lam_hip_ctx *c)
     release_hub(c);
     for (auto &s : c->sh) { free_shard(s); release_handles(s); }
     if (c->direct_err) { (void)hipHostFree(c->direct_err); c->direct_err = nullptr; }
+}
+
+// Environment LAM_HIP_EXCHANGE = default exchange of new contexts (drivers have no other way to choose one).  The direct
+// exchange (2) is EXPERIMENTAL -- never yet run on separate GPUs -- and lam_hip_cg_init + lam_hip_cg_iterate do not check
+// themselves the way lam_hip_solve does, so the environment alone must not make it anybody's default: it is honoured only
+// together with LAM_HIP_EXPERIMENTAL_DIRECT=1; lam_hip_set_option("exchange", 2) stays the explicit opt-in.
+int64_t exchange_from_env(int64_t dflt)
+{
+    const char *ex = getenv("LAM_HIP_EXCHANGE");
+    if (ex == nullptr || *ex == '\0') return dflt;
+    const int v = atoi(ex);
+    if (v == 2) {
+        const char *ok = getenv("LAM_HIP_EXPERIMENTAL_DIRECT");
+        if (!(ok && *ok && strcmp(ok, "0") != 0)) {
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true))
+                fprintf(stderr, "lam_hip: LAM_HIP_EXCHANGE=2 (direct exchange, experimental) ignored: set LAM_HIP_EXPERIMENTAL_DIRECT=1 as well\n");
+            return dflt;
+        }
+    }
+    return (v >= 0 && v <= 2) ? v : dflt;
 }
 
 int create_common(lam_hip_ctx *c)
@@ -1125,7 +1163,8 @@ int enqueue_shard_direct(lam_hip_ctx *c, ShardBase &s, int k, double rel_error, 
         LAMCHK(set_dev(c, s));
         const int P = c->total_shards;
         const int me = s.index;
-        const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
+        const unsigned long long seq = c->seq_base + (unsigned)k;
+        c->seq_span = std::max<uint64_t>(c->seq_span, (uint64_t)k + 1);
         // 1. GEMV.  p for this iteration: the own slice is local; the others were stored into this rank's
         //    replica by the peers' update_p of iteration k-1 (k == 1: by cg_init) -- wait for their flags
         //    behind the own-slice panel.
@@ -1473,7 +1512,8 @@ int enqueue_persist_chunk(lam_hip_ctx *c, int k_first, int count, double rel_err
             a.bc_pap = c->persist_bc; a.bc_rr = c->persist_bc + kVecBlocksMax;
             a.W = c->persist_W; a.vec_blocks = s.vec_blocks;
             a.npairs = (uint32_t)(c->n / 2); a.ntiles = (uint32_t)((c->n + 4095) / 4096);
-            a.epoch_hi = (unsigned long long)c->epoch << 32;
+            a.seq_base = c->seq_base;
+            c->seq_span = std::max<uint64_t>(c->seq_span, (uint64_t)(k_first + count));
             a.ticks = c->persist_ticks;
             hipLaunchKernelGGL((cg_persist_kernel<TA, TV>), dim3(c->persist_W + 1), dim3(kBlock), 0, s.stream, a);
             LAUNCHED(c);
@@ -1488,7 +1528,9 @@ int decide_persistent(lam_hip_ctx *c) { c->persist_active = false; return 0; }
 int do_cg_init(lam_hip_ctx *c)
 {
     c->cg_direct = false;
-    c->epoch++;                    // mailbox tags = (epoch << 32) | iteration: never repeated across solves
+    c->epoch++;
+    c->seq_base += c->seq_span;    // hand-over numbers never restart (see seq_base)
+    c->seq_span = 1;
     for (auto &sh_ : c->sh) sh_.waited_k = 0;
     if (c->direct_err) memset(c->direct_err, 0, 64);
     if (c->exchange2_wanted()) {
@@ -1592,7 +1634,8 @@ int phase_xr(lam_hip_ctx *c, ShardBase &s, int k, double rel_error)
     red_source(c, s, false, true, fin_a, &red, &nred);
     if (c->fuse_active) {
         // one shard: phases B and C in ONE launch; the r.r total travels through the context's own mailbox
-        const unsigned long long seq = ((unsigned long long)c->epoch << 32) | (unsigned)k;
+        const unsigned long long seq = c->seq_base + (unsigned)k;
+        c->seq_span = std::max<uint64_t>(c->seq_span, (uint64_t)k + 1);
         Finalize fr = no_finalize(c);
         fr.active = 1; fr.seq = seq;                 // one shard: the total goes straight to the broadcast slot
         BlockCounts nb;
@@ -1671,13 +1714,33 @@ Progress read_progress(const ShardBase &s)
 // Wait until iteration `target` has made its stop decision (update_p_kernel's progress word in pinned memory), or
 // some iteration has stopped, or a bounded in-kernel wait has expired.  No event per iteration is involved: an event
 // record is a marker packet between the iteration's kernels.  A stream error (a fault, a lost device) ends the wait.
+// The host does not burn a core while it waits (round 4; in rank mode that was one spinning core per GPU next to RCCL's
+// proxy threads): after a short spin -- an iteration that is about to report costs nothing -- it SLEEPS between polls,
+// for a quarter of the iteration time observed so far (clamped to 20 us .. 1 ms).  The host enqueues kLag iterations
+// ahead of the one it awaits, so a wake-up that comes a whole iteration late is still free: the queue never drains.
 int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
 {
-    unsigned spins = 0;
+    unsigned polls = 0;
+    double t_query = 0.0;
     for (;;) {
         const Progress pr = read_progress(s0);
-        if (pr.iters >= target || pr.stop_at != 0 || *(volatile int *)c->direct_err != 0) { *out = pr; return 0; }
-        if ((++spins & 4095u) == 0) {
+        if (pr.iters >= target || pr.stop_at != 0 || *(volatile int *)c->direct_err != 0) {
+            // iteration-time estimate: progress made since the previous successful wait / time since then
+            const double t = now_s();
+            if (c->prog_t > 0.0 && pr.iters > c->prog_iter && pr.stop_at == 0) {
+                const double per = (t - c->prog_t) / (double)(pr.iters - c->prog_iter);
+                c->iter_est_s = c->iter_est_s > 0.0 ? 0.75 * c->iter_est_s + 0.25 * per : per;
+            }
+            c->prog_t = t;
+            c->prog_iter = pr.iters;
+            *out = pr;
+            return 0;
+        }
+        if (++polls <= 64u) { __builtin_ia32_pause(); continue; }
+        const double t = now_s();
+        if (t_query == 0.0) t_query = t;
+        if (t - t_query > 2e-3) {                       // liveness: look at the stream every 2 ms of waiting
+            t_query = t;
             const hipError_t e = hipStreamQuery(s0.stream);
             if (e == hipSuccess) {
                 // everything enqueued has run: the word is final (it may have been written since the read above)
@@ -1686,10 +1749,10 @@ int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
                 return fail(c, LAM_HIP_EHIP, "iteration %d was enqueued but never reported (progress word at %d)", target, again.iters);
             }
             if (e != hipErrorNotReady) return fail(c, LAM_HIP_EHIP, "stream error while iterating: %s", hipGetErrorString(e));
-            sched_yield();
-        } else {
-            __builtin_ia32_pause();
         }
+        const double nap = std::min(1e-3, std::max(20e-6, 0.25 * c->iter_est_s));
+        struct timespec ts = {0, (long)(nap * 1e9)};
+        (void)nanosleep(&ts, nullptr);
     }
 }
 
@@ -1771,7 +1834,7 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
     // The join goes through shard 0's stream when there are more than two shards (2(P-1)+1 runtime calls instead of P(P-1)).
     if (n_shards > 1) c->opt_exchange = 1;
     c->opt_join = n_shards > 2 ? 1 : 0;
-    if (const char *ex = getenv("LAM_HIP_EXCHANGE")) { const int v = atoi(ex); c->opt_exchange = (v == 1 || v == 2) ? v : 0; }
+    c->opt_exchange = exchange_from_env(c->opt_exchange);
     int rc = create_common(c.get());
     if (rc != 0) { abandon(c.get()); return rc; }
     *out = c.release();
@@ -1807,7 +1870,7 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     const char *force = getenv("LAM_HIP_FORCE_RCCL");
     const bool forced = force && *force && strcmp(force, "0") != 0;
     c->rank_mode = nranks > 1 || forced;
-    if (const char *ex = getenv("LAM_HIP_EXCHANGE")) c->opt_exchange = atoi(ex);   // default exchange for this context
+    c->opt_exchange = exchange_from_env(c->opt_exchange);   // default exchange for this context
     c->sh.resize(1);
     c->sh[0].index = rank;
     c->sh[0].dev = device_id;
@@ -2253,7 +2316,13 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     if (!c->cg_ready) return fail(c, LAM_HIP_ESTATE, "call lam_hip_cg_init first");
     if (iters < 0) return fail(c, LAM_HIP_EINVAL, "iters must be >= 0");
     const double t0 = now_s();
+    const uint64_t cpu0 = thread_cpu_ns();
+    struct CpuAccount {            // every exit path
+        lam_hip_ctx *c; uint64_t t0;
+        ~CpuAccount() { c->host_cpu_ns += thread_cpu_ns() - t0; }
+    } cpu_account{c, cpu0};
     ShardBase &s0 = c->sh[0];
+    c->prog_t = 0.0;               // the estimate of the iteration time carries over, the reference point does not
     double gemv_ms = 0.0;
     int gemv_samples = 0;
     int enq = 0;
@@ -2309,6 +2378,13 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             c->enqueue_ns += (uint64_t)((now_s() - te) * 1e9);
             enq++;
         }
+    }
+    if (enq > 0) {
+        // the last iterations are still in the queue: wait for the last one's report with the sleeping poll (a
+        // hipStreamSynchronize would spin a core for up to kLag iterations), then synchronise for real
+        Progress pr;
+        LAMCHK(set_dev(c, s0));
+        LAMCHK(await_progress(c, s0, k_first + enq - 1, &pr));
     }
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));
@@ -2803,6 +2879,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "exchange_hub")) *value = c->opt_hub;
     else if (!strcmp(name, "assume_cus")) *value = c->opt_assume_cus;
     else if (!strcmp(name, "host_enqueue_ns")) *value = (int64_t)c->enqueue_ns;
+    else if (!strcmp(name, "host_cpu_ns")) *value = (int64_t)c->host_cpu_ns;
     else if (!strcmp(name, "hip_calls_launch")) *value = (int64_t)c->n_launch.load();
     else if (!strcmp(name, "hip_calls_record")) *value = (int64_t)c->n_record.load();
     else if (!strcmp(name, "hip_calls_wait")) *value = (int64_t)c->n_wait.load();

@@ -159,20 +159,46 @@ struct Finalize {
 // the ranks are threads of one process) and the producer kernels store straight into them over xGMI:
 //   * the reducer workgroup of the GEMV / update_xr launch writes the rank's partial dot product into
 //     slot [rank] of EVERY rank's mailbox: value (system-scope write-through store), drain, then the tag
-//     `seq` = (solve epoch << 32) | iteration.  The consumer kernel (update_xr / update_p) polls the P tags
+//     `seq` = the context's hand-over number of that iteration.  The consumer kernel (update_xr / update_p) polls the P tags
 //     of its own mailbox and sums the P values in rank order: the fused, latency-optimal form of the two
 //     scalar all-reduces, deterministic and bit-identical to the RCCL exchange;
 //   * update_p stores its p slice into every rank's p replica with system-scope write-through stores,
 //     drains them, and raises pflag[rank][workgroup] = seq in every mailbox; a 1-workgroup wait_p_kernel
 //     in front of the next GEMV (behind its own-slice panel) polls those flags: the direct all-gather.
-// Mailboxes are fine-grained (uncached) device memory; tags never repeat (epoch), so nothing is ever
+// Mailboxes are fine-grained (uncached) device memory; hand-over numbers grow by one per iteration and never restart, so nothing is ever
 // reset and a slot can be read by any number of workgroups.  Every poll is bounded (SpinGuard):
 // a peer that never shows up ends in an error flag in pinned host memory, not in a hang.
 // ---------------------------------------------------------------------------------------------
+// A {value, tag} hand-over as TWO SELF-VALIDATING 8-byte words (round 4): word h carries half h of the double's
+// bits in its low 32 bits and the 32-bit tag in its high 32 bits.  Each word is written by ONE relaxed atomic store and read
+// by ONE relaxed atomic load, and an 8-byte atomic object is its own ready flag: the reader takes the value only from words
+// whose tag matches, so nothing is assumed about the order of accesses to DIFFERENT locations -- no fence, no drain, and no
+// data race in the HIP memory model's terms.  (Rounds 2-3 wrote {value; s_waitcnt vmcnt(0); tag} and read the tag and then
+// the value with two relaxed loads: correct on this hardware, which returns loads in order, but formally a race.)
+// Tags are the low 32 bits of a hand-over number that grows by one per iteration over the whole life of a context
+// (lam_hip.hip, seq_base): a slot is rewritten every iteration, so a stale tag is the previous iteration's, never equal.
 struct MailSlot {
-    unsigned long long value_bits;    // the double, written first
-    unsigned long long seq;           // written after the value has been drained to memory
+    unsigned long long w[2];
 };
+template <int SCOPE>
+__device__ __forceinline__ void handover_store(MailSlot *slot, double value, unsigned long long seq)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(value), tag = (seq & 0xffffffffull) << 32;
+    __hip_atomic_store(&slot->w[0], tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, SCOPE);
+    __hip_atomic_store(&slot->w[1], tag | (bits >> 32), __ATOMIC_RELAXED, SCOPE);
+}
+// true (and the value) once BOTH words carry the tag; *seen = what the first word's tag was (diagnostics)
+template <int SCOPE>
+__device__ __forceinline__ bool handover_try_load(const MailSlot *slot, unsigned long long seq, double *value, unsigned *seen)
+{
+    const unsigned long long w0 = __hip_atomic_load(&slot->w[0], __ATOMIC_RELAXED, SCOPE);
+    const unsigned long long w1 = __hip_atomic_load(&slot->w[1], __ATOMIC_RELAXED, SCOPE);
+    const unsigned tag = (unsigned)(seq & 0xffffffffull);
+    *seen = (unsigned)(w0 >> 32);
+    if ((unsigned)(w0 >> 32) != tag || (unsigned)(w1 >> 32) != tag) return false;
+    *value = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+    return true;
+}
 struct Mail {
     MailSlot pap[kMaxShards];
     MailSlot rr[kMaxShards];
@@ -209,21 +235,20 @@ __device__ __forceinline__ double mail_sum(const MailWait &w, double *s_red)
     if ((int)threadIdx.x < w.n) {
         const MailSlot *m = w.slots + threadIdx.x;
         SpinGuard guard;
-        unsigned long long seen;
-        while ((seen = ld_sys(&m->seq)) != w.seq) {
+        unsigned seen;
+        while (!handover_try_load<__HIP_MEMORY_SCOPE_SYSTEM>(m, w.seq, &v, &seen)) {
             if (guard.slow_path()) {
             // an expired wait anywhere (this kernel or an earlier one) ends all waiting: the solve has failed
             if (*(volatile int *)w.host_err != 0) break;
             if (guard.expired()) {
-                w.host_err[1] = (int)threadIdx.x; w.host_err[2] = (int)(unsigned)w.seq; w.host_err[3] = (int)(unsigned)seen;
-                w.host_err[4] = (int)(w.seq >> 32); w.host_err[5] = (int)(seen >> 32);
+                w.host_err[1] = (int)threadIdx.x; w.host_err[2] = (int)(unsigned)w.seq; w.host_err[3] = (int)seen;
+                w.host_err[4] = (int)(w.seq >> 32); w.host_err[5] = 0;
                 *(volatile int *)w.host_err = 2;
                 break;
             }
             }
             __builtin_amdgcn_s_sleep(4);
         }
-        v = __longlong_as_double((long long)ld_sys(&m->value_bits));
     }
     return block_sum(v, s_red);
 }
@@ -299,11 +324,8 @@ __device__ __forceinline__ void post_total(const Finalize &f, double total)
     if (!f.mail) {
         for (int j = 0; j < f.dst.n; j++) reinterpret_cast<double *>(f.dst.p[j])[f.slot] = total;
     } else {
-        // direct exchange: value into every rank's mailbox, drain, then the tags
-        for (int j = 0; j < f.dst.n; j++)
-            st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->value_bits, (unsigned long long)__double_as_longlong(total));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int j = 0; j < f.dst.n; j++) st_sys(&reinterpret_cast<MailSlot *>(f.dst.p[j])->seq, f.seq);
+        // direct exchange: the tagged words into every rank's mailbox (system-scope write-through stores)
+        for (int j = 0; j < f.dst.n; j++) handover_store<__HIP_MEMORY_SCOPE_SYSTEM>(reinterpret_cast<MailSlot *>(f.dst.p[j]), total, f.seq);
     }
 }
 
@@ -313,8 +335,8 @@ __device__ __forceinline__ void reduce_partials(double *partial, int n, const Fi
 }
 
 // Hand-over INSIDE a launch (update_fused_kernel): the reducer workgroup publishes a scalar for the launch's
-// other workgroups in ordinary device memory -- value (agent-scope write-through store), drain, tag -- and they
-// poll the tag with agent-scope loads.  One thread polls; the value reaches the workgroup through block_sum.
+// other workgroups in ordinary device memory -- two tagged words (MailSlot), agent-scope write-through stores -- and
+// they poll them with agent-scope loads.  One thread polls; the value reaches the workgroup through block_sum.
 // Every listener has a LINE OF ITS OWN (BcastLine, 128 B): hundreds of workgroups polling one word serialise at the
 // memory side and the writer's store queues behind them -- measured 0.2-0.35 us per polling workgroup, 45-90 us per
 // iteration with 256 of them.  The reducer's threads write the lines in parallel.
@@ -325,11 +347,7 @@ struct BcastLine {
 };
 __device__ __forceinline__ void bcast_post(BcastLine *lines, int nlisteners, double value, unsigned long long seq)
 {
-    for (int t = threadIdx.x; t < nlisteners; t += kBlock)
-        __hip_atomic_store(&lines[t].s.value_bits, (unsigned long long)__double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int t = threadIdx.x; t < nlisteners; t += kBlock)
-        __hip_atomic_store(&lines[t].s.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = threadIdx.x; t < nlisteners; t += kBlock) handover_store<__HIP_MEMORY_SCOPE_AGENT>(&lines[t].s, value, seq);
 }
 __device__ __forceinline__ double bcast_wait(const BcastLine *line, unsigned long long seq, int *host_err, double *s_red)
 {
@@ -337,20 +355,19 @@ __device__ __forceinline__ double bcast_wait(const BcastLine *line, unsigned lon
     double v = 0.0;
     if (threadIdx.x == 0) {
         SpinGuard guard;
-        unsigned long long seen;
-        while ((seen = __hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != seq) {
+        unsigned seen;
+        while (!handover_try_load<__HIP_MEMORY_SCOPE_AGENT>(slot, seq, &v, &seen)) {
             if (guard.slow_path()) {
             if (*(volatile int *)host_err != 0) break;
             if (guard.expired()) {
-                host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
-                host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
+                host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)seen;
+                host_err[4] = (int)(seq >> 32); host_err[5] = 0;
                 *(volatile int *)host_err = 4;
                 break;
             }
             }
             __builtin_amdgcn_s_sleep(4);
         }
-        v = __longlong_as_double((long long)__hip_atomic_load(&slot->value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     return block_sum(v, s_red);
 }
@@ -1365,6 +1382,9 @@ update_p_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int k, 
         for (int j = 0; j < pdst.n; j++)
             __hip_atomic_store(reinterpret_cast<TV *>(pdst.p[j]) + row0 + i, pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // every thread: its slice stores happen-before the workgroup's flag stores (system-scope release fence, then the
+    // workgroup barrier, then relaxed flag stores; the reader pairs it with an acquire fence behind its poll)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if ((int)threadIdx.x < post.n && (int)threadIdx.x != post.rank)
@@ -1393,6 +1413,9 @@ __device__ __forceinline__ void wait_p_flags(const Mail *mine, int nranks, int r
             }
         }
     }
+    // the peers' slices (stored before their release fences) happen-before everything this thread -- and, through the
+    // end of the kernel, the next kernel on this stream -- does from here on
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1484,6 +1507,7 @@ update_fused_kernel(const double *__restrict__ red, int nred, CgScalars *sc, int
         for (int j = 0; j < pdst.n; j++)
             __hip_atomic_store(reinterpret_cast<TV *>(pdst.p[j]) + row0 + i, pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // as in update_p_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if ((int)threadIdx.x < post.n && (int)threadIdx.x != post.rank)
@@ -1640,7 +1664,7 @@ struct PersistArgs {
     BcastLine *bc_rr;             // [W]
     int W, vec_blocks;
     uint32_t npairs, ntiles;
-    unsigned long long epoch_hi;  // solve epoch << 32: tags never repeat
+    unsigned long long seq_base;  // hand-over number of iteration k = seq_base + k (grows over the life of the context)
     unsigned long long *ticks;    // [0] += constant-rate ticks (100 MHz) spent in GEMV phases, [1] += phases
 };
 
@@ -1678,23 +1702,22 @@ __device__ __forceinline__ double persist_wait(const BcastLine *line, unsigned l
     const MailSlot *slot = &line->s;
     double v = 0.0;
     if (threadIdx.x == 0) {
-        unsigned polls = 0;
-        unsigned long long t0 = 0, seen;
-        while ((seen = __hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != seq) {
+        unsigned polls = 0, seen;
+        unsigned long long t0 = 0;
+        while (!handover_try_load<__HIP_MEMORY_SCOPE_AGENT>(slot, seq, &v, &seen)) {
             if ((++polls & 8191u) == 0) {
                 const unsigned long long now = (unsigned long long)clock64();
                 if (t0 == 0) t0 = now | 1ull;
                 if (*(volatile int *)host_err != 0) break;
                 if (now - t0 > kSpinTimeoutCycles) {
-                    host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)(unsigned)seen;
-                    host_err[4] = (int)(seq >> 32); host_err[5] = (int)(seen >> 32);
+                    host_err[1] = -1; host_err[2] = (int)(unsigned)seq; host_err[3] = (int)seen;
+                    host_err[4] = (int)(seq >> 32); host_err[5] = 0;
                     *(volatile int *)host_err = 4;
                     break;
                 }
             }
             if (polls < 512u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
         }
-        v = __longlong_as_double((long long)__hip_atomic_load(&slot->value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     return block_sum(v, s_red);
 }
@@ -1725,7 +1748,7 @@ cg_persist_kernel(PersistArgs<TA, TV> a)
         // ---- the reducer workgroup: both hand-overs of every iteration
         unsigned long long t_prev = wall_clock64();
         for (int it = 0; it < a.k_count; it++) {
-            const unsigned long long seq = a.epoch_hi | (unsigned)(a.k_first + it);
+            const unsigned long long seq = a.seq_base + (unsigned)(a.k_first + it);
             const double pAp = reduce_partials_sum(a.part_gemv, (int)a.npairs, s_red, a.host_err);
             const unsigned long long t_gemv_end = wall_clock64();
             bcast_post(a.bc_pap, a.vec_blocks, pAp, seq);
@@ -1745,7 +1768,7 @@ cg_persist_kernel(PersistArgs<TA, TV> a)
     int cur = 0;                                  // pbuf[cur]: the last explicitly stored p
     for (int it = 0; it < a.k_count; it++) {
         const int k = a.k_first + it;
-        const unsigned long long seq = a.epoch_hi | (unsigned)k;
+        const unsigned long long seq = a.seq_base + (unsigned)k;
         const bool direct = it == 0;              // p_{k-1} is explicit in pbuf[cur]; else p_{k-1} = r + beta pbuf[cur]
         const TV *pold = a.pbuf[cur];
         TV *pdst = a.pbuf[cur ^ 1];

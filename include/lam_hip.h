@@ -219,7 +219,10 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   their partial dot products and p slices straight into them over xGMI, tagged with the
  *                   iteration; consumers poll the tags (bounded).  Results are bit-identical to exchange 0.
  *                   Falls back to 0 when a mapping cannot be made (all ranks agree).  Re-run cg_init/solve
- *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts.
+ *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts (the value 2 only
+ *                   together with LAM_HIP_EXPERIMENTAL_DIRECT=1: lam_hip_cg_init + lam_hip_cg_iterate do not check
+ *                   themselves the way lam_hip_solve does, so the environment alone cannot make the experimental exchange
+ *                   anybody's default; cross-GPU parity of exchange 2 is UNPINNED until it has run on separate devices).
  *                   ONE PROCESS WITH SEVERAL SHARDS (lam_hip_create): 1 (DEFAULT) = gather-Ap: every shard's GEMV stores its Ap
  *                   slice and its p.Ap partial straight into every shard's gather buffer (peer stores over xGMI), ONE event
  *                   join per iteration, r and p full-length on every shard and updated redundantly -- the layout of the
@@ -272,6 +275,10 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   Measured host cost of both: profiles/r03_host_enqueue_cost.txt.  Same bits in every combination.
  *   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "host_enqueue_ns" (get only): runtime calls issued and host
  *                   time spent by the iteration loop so far (diagnostics, tools/host_enqueue_cost.py).
+ *   "host_cpu_ns"   (get only) CPU time (CLOCK_THREAD_CPUTIME_ID) the calling thread has spent inside lam_hip_cg_iterate:
+ *                   the host SLEEPS between its polls of the iteration's progress word (a quarter of the observed iteration
+ *                   time, 20 us .. 1 ms; it runs 4 iterations ahead of the one it awaits, so the queue never drains), it
+ *                   does not spin a core per solve.
  *   "reuse_matrix"  1 (default) = lam_hip_set_problem keeps the matrix allocation when it is large enough for the new
  *                   problem (grow-only: a context never hands tens of GB back between problems); 0 = free + allocate.
  *   "upload_staging" lam_hip_upload_rows: 1 = copy through two pinned staging buffers (host memcpy overlapped

@@ -66,8 +66,10 @@ def test_getopt_driver_file_mode_against_golden_solution(golden, oracle, tmp_pat
 
 @pytest.mark.parametrize("exe,env", [(ONE_EXE, {}), (MULTI_EXE, {"LAM_NUM_SHARDS": "3"}),
                                      # the one-process class on the in-kernel flag exchange (shards share GPU 0 here: on request)
-                                     (MULTI_EXE, {"LAM_NUM_SHARDS": "4", "LAM_HIP_EXCHANGE": "2", "LAM_HIP_DIRECT_SAME_DEVICE": "1",
-                                                  "GPU_MAX_HW_QUEUES": "12"})])
+                                     (MULTI_EXE, {"LAM_NUM_SHARDS": "4", "LAM_HIP_EXCHANGE": "2", "LAM_HIP_EXPERIMENTAL_DIRECT": "1",
+                                                  "LAM_HIP_DIRECT_SAME_DEVICE": "1", "GPU_MAX_HW_QUEUES": "12"}),
+                                     # ... and on the three-join event exchange (the default is gather-Ap)
+                                     (MULTI_EXE, {"LAM_NUM_SHARDS": "2", "LAM_HIP_EXCHANGE": "0"})])
 def test_positional_drivers(golden, oracle, tmp_path, exe, env):
     """matrix rhs sol max_iters rel_error; prints the reference's 'Converged in K iterations' line."""
     for g in golden["file_mode"]:
@@ -242,7 +244,7 @@ def test_mpi_driver_other_exchanges_across_processes(tmp_path, mock_async, excha
     if not (os.path.exists(exe) and os.path.exists(mpiexec)):
         pytest.skip("MPI driver not built (make mpi)")
     env = {"LD_PRELOAD": mock_async, "GPU_MAX_HW_QUEUES": "8", "MOCK_RCCL_STATS_FILE": str(tmp_path / "st.jsonl"),
-           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LAM_HIP_EXCHANGE": exchange}
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LAM_HIP_EXCHANGE": exchange, "LAM_HIP_EXPERIMENTAL_DIRECT": "1"}
     genv = []
     for k, v in env.items():
         genv += ["-genv", k, v]

@@ -690,6 +690,23 @@ def test_gemv_timing_can_be_sampled_or_off(lam):
     assert res[0] == res[1] == res[2]
 
 
+def test_host_does_not_spin_a_core_per_solve(lam):
+    """lam_hip_cg_iterate follows the iteration through the progress word and SLEEPS between polls (it runs 4 iterations
+    ahead of the one it awaits, so a late wake-up is free): at N=32768 (1.24 ms per iteration) the calling thread's CPU
+    time stays a small fraction of the wall time -- rounds 1-3 spent 100 % -- and the iteration rate does not suffer."""
+    with lam.Solver(lam.F64) as s:
+        s.generate_random_spd(32768, 1234, 1e6)
+        s.generate_random_rhs(1235)
+        s.cg_init()
+        s.cg_iterate(10, 0.0)
+        c0 = s.get_option("host_cpu_ns")
+        st = s.cg_iterate(150, 0.0)
+        cpu = (s.get_option("host_cpu_ns") - c0) * 1e-9
+    assert st["num_iters"] == 161
+    assert cpu <= 0.15 * st["t_total"], (cpu, st["t_total"])
+    assert st["t_iter"] < 1.33e-3, st            # 8.59 GB per iteration at >= 6.5 TB/s + the vector step
+
+
 def test_stop_is_seen_without_events(lam, oracle):
     """The stopping iteration reaches the host through the progress word: a solve that converges after a few
     iterations returns the converging iteration however far ahead the host had enqueued, and later calls are no-ops."""

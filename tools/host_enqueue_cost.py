@@ -67,13 +67,14 @@ def main():
                 for _ in range(3):
                     s.cg_init()
                     s.cg_iterate(20, 0.0)
-                    c0, h0 = calls(s), s.get_option("host_enqueue_ns")
+                    c0, h0, u0 = calls(s), s.get_option("host_enqueue_ns"), s.get_option("host_cpu_ns")
                     st = s.cg_iterate(iters, 0.0)
-                    c1, h1 = calls(s), s.get_option("host_enqueue_ns")
+                    c1, h1, u1 = calls(s), s.get_option("host_enqueue_ns"), s.get_option("host_cpu_ns")
                     if best is None or st["t_iter"] < best:
                         best = st["t_iter"]
                         per = {k: (c1[k] - c0[k]) / iters for k in CALLS}
                         host = (h1 - h0) / iters * 1e-3
+                        cpu = (u1 - u0) / iters * 1e-3
                 x = s.solution()
                 if ref is None:
                     ref = x
@@ -81,7 +82,7 @@ def main():
                 # full-length partials: equal to rounding
                 same = bool(np.array_equal(x, ref)) or ((exchange == 1 or (exchange == 2 and overlap == 1)) and np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref))
                 kind = {0: "", 1: " gather-Ap join-via-shard0" if overlap else " gather-Ap all-to-all", 2: " split" if overlap else " nosplit"}[exchange]
-                print(f"P={P} exchange={s.get_option('exchange_effective')}{kind} host_threads={threads} exchange_hub={hub} gemv_timing={timing}: HOST {host:7.1f} us/iteration to enqueue, wall {best*1e6:7.1f} us/iteration   calls/iteration: "
+                print(f"P={P} exchange={s.get_option('exchange_effective')}{kind} host_threads={threads} exchange_hub={hub} gemv_timing={timing}: HOST {host:7.1f} us/iteration to enqueue, wall {best*1e6:7.1f} us/iteration, thread CPU {cpu:7.1f} us/iteration   calls/iteration: "
                       + " ".join(f"{k}={per[k]:.1f}" for k in CALLS) + f"   same result as first variant: {same}", flush=True)
                 assert same
 
