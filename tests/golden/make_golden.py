@@ -20,6 +20,11 @@ SURVEY.md section 4 finding 2):
    (reference: challenge/main/test/test_CG_CPU_MPI_OMP.cpp, solver
    LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:71-142).  Output: the CSV line.
 
+3. (round 4) File mode in FLOAT -- oracle/_ref/ref_float_harness.out: the reference's ConjugateGradient_CPU_OMP class
+   instantiated with <float> by a 20-line main() of ours (oracle/ref_float_harness.cpp; the reference's drivers hard-code
+   <double>, its GPU classes are instantiated with float: ...CUDA_NCCL.cu:767).  Inputs: the fp64 fixtures' systems rounded to
+   float (<name>.f32.matrix.bin / .f32.rhs.bin).  `make_golden.py --float-only` adds just these to an existing golden.json.
+
 Fixtures written: <name>.matrix.bin / .rhs.bin (inputs), <name>.sol.bin (reference output,
 byte-for-byte, including the garbage upper half of its cols word), golden.json (numbers).
 These are data; no reference source text is stored.
@@ -64,7 +69,42 @@ def run(cmd, **kw):
     return out.stdout
 
 
+REF_F32 = os.path.join(ROOT, "oracle", "_ref", "ref_float_harness.out")
+
+
+def float_fixtures(golden):
+    """The reference's CPU class with <float> (see the module docstring, 3.)."""
+    if not os.path.exists(REF_F32):
+        sys.exit("build the reference first: make -C oracle ref")
+    golden["file_mode_f32"] = []
+    for n, seed, max_iters, tol in [(64, 7, 10000, 1e-5), (128, 42, 10000, 1e-5), (64, 7, 5, 1e-5), (128, 42, 40, 1e-9)]:
+        name = f"spd_n{n}_s{seed}"
+        a, b = make_spd(n, seed)                      # the very system of the fp64 fixture, rounded to float
+        mpath, bpath = os.path.join(HERE, name + ".f32.matrix.bin"), os.path.join(HERE, name + ".f32.rhs.bin")
+        for path, arr in ((mpath, a), (bpath, b)):
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            with open(path, "wb") as f:
+                f.write(struct.pack("=QQ", arr.shape[0], arr.shape[1]))
+                f.write(arr.tobytes())
+        tag = f"{name}_f32_i{max_iters}_e{tol:g}"
+        spath = os.path.join(HERE, tag + ".sol.bin")
+        out = run([REF_F32, mpath, bpath, spath, str(max_iters), repr(tol)])
+        m = re.search(r"(Converged in|Did not converge in) (\d+) iterations, relative error is (\S+)", out)
+        assert m, out
+        golden["file_mode_f32"].append({"name": name, "tag": tag, "n": n, "seed": seed, "max_iters": max_iters, "tol": tol,
+                                        "converged": m.group(1).startswith("Converged"), "iters_printed": int(m.group(2)),
+                                        "rel_err_printed": float(m.group(3))})
+        print(tag, m.group(0))
+
+
 def main():
+    if "--float-only" in sys.argv:
+        with open(os.path.join(HERE, "golden.json")) as f:
+            golden = json.load(f)
+        float_fixtures(golden)
+        with open(os.path.join(HERE, "golden.json"), "w") as f:
+            json.dump(golden, f, indent=1)
+        return
     if not (os.path.exists(REF_OMP) and os.path.exists(REF_MPI)):
         sys.exit("build the reference first: make -C oracle ref")
     golden = {"file_mode": [], "gen_mode": []}
@@ -141,6 +181,7 @@ def main():
                          "iters_printed": int(m.group(1)), "rel_err_printed": float(m.group(2))}
     print("heat cg", m.group(0))
 
+    float_fixtures(golden)
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(golden, f, indent=1)
 

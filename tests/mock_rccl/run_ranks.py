@@ -4,9 +4,14 @@ LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl_async.hip: stream
 synchronises hosts or streams -- the semantics of the real library).  Prints one JSON line.
 
 usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1] [--iters K] [--tol T]
-                             [--chunk C]    with mode in {tridiag, spd}
+                             [--chunk C]    with mode in {tridiag, spd, file}
 --chunk C runs the solve as repeated lam_hip_cg_iterate(C) calls (the stop has to be noticed across
-calls, and every rank must leave the loop after the same call)."""
+calls, and every rank must leave the loop after the same call).
+mode file: --matrix / --rhs name files in the reference's format (every rank reads its own row block), N is ignored.
+Unless --no-single is given the same system is also solved on ONE shard and -- n <= 4096 -- by the CPU ORACLE with the
+same number of (emulated) ranks (oracle.cg_solve(..., P=P): the reference's MPI recurrence, CPU_MPI_OMP.hpp:71-142), and
+the residual is recomputed with numpy: every multi-rank case is tied to the reference algorithm, not only to another
+run of the HIP path."""
 import argparse, hashlib, importlib, json, os, sys, threading
 import numpy as np
 
@@ -19,7 +24,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("P", type=int)
     ap.add_argument("n", type=int)
-    ap.add_argument("mode", choices=["tridiag", "spd"])
+    ap.add_argument("mode", choices=["tridiag", "spd", "file"])
+    ap.add_argument("--matrix", default=None)
+    ap.add_argument("--rhs", default=None)
+    ap.add_argument("--save-x", default=None, help="write rank 0's solution vector here (.npy)")
     ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--exchange", type=int, default=0)
     ap.add_argument("--finalize", type=int, default=1)
@@ -32,6 +40,9 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the single-shard comparison run")
     a = ap.parse_args()
     P, n, mode = a.P, a.n, a.mode
+    if mode == "file":
+        with open(a.matrix, "rb") as fh:
+            n = int(np.frombuffer(fh.read(8), dtype=np.uint64)[0])
     DT = {"f64": lam.F64, "f32": lam.F32, "bf16": lam.BF16}[a.dtype]
     vdt = np.float64 if a.dtype == "f64" else np.float32
     tol = a.tol if a.tol is not None else (1e-9 if mode == "tridiag" else 1e-10)
@@ -43,7 +54,9 @@ def main():
     xprobe = (np.arange(n, dtype=np.float64) / n).astype(vdt)
 
     def setup(s):
-        if mode == "tridiag":
+        if mode == "file":
+            assert s.load_matrix_from_file(a.matrix) and s.load_rhs_from_file(a.rhs)
+        elif mode == "tridiag":
             s.generate_matrix(n)
             s.generate_rhs()
         else:
@@ -95,6 +108,8 @@ def main():
         "ranks_identical": bool(all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"]
                                     and o["err"] == out[0]["err"] and np.array_equal(out[0]["y"], o["y"]) for o in out)),
     }
+    if a.save_x:
+        np.save(a.save_x, out[0]["x"])
     if not a.no_single:
         # the same system on one shard, no RCCL
         with lam.Solver(DT) as s:
@@ -102,8 +117,19 @@ def main():
             s.solve(iters, tol)
             x1, it1 = s.solution(), s.stats["num_iters"]
             y1 = s.gemv(xprobe)
+            if n <= 4096:
+                A_host, b_host = s.download_rows(0, n), s.rhs()       # what the device holds (bf16: the rounded matrix)
         res.update(iters_single=it1, x_vs_single=float(np.linalg.norm(out[0]["x"] - x1) / np.linalg.norm(x1)),
                    gemv_vs_single=float(np.max(np.abs(out[0]["y"] - y1)) / np.max(np.abs(y1))))
+        if n <= 4096:
+            # ... and the reference algorithm itself on the same system, with the same number of ranks
+            from oracle import pyoracle
+            x_or, st_or = pyoracle.cg_solve(A_host.astype(vdt), b_host.astype(vdt), iters, tol, P=P)
+            A64, b64, x64 = A_host.astype(np.float64), b_host.astype(np.float64), out[0]["x"].astype(np.float64)
+            res.update(iters_oracle=st_or["num_iters"], converged_oracle=bool(st_or["converged"]), rel_err_oracle=st_or["rel_err"],
+                       x_vs_oracle=float(np.linalg.norm(x64 - x_or) / np.linalg.norm(x_or)),
+                       residual_numpy=float(np.linalg.norm(b64 - A64 @ x64) / np.linalg.norm(b64)),
+                       residual_numpy_oracle=float(np.linalg.norm(b64 - A64 @ x_or.astype(np.float64)) / np.linalg.norm(b64)))
     print(json.dumps(res))
 
 

@@ -322,7 +322,9 @@ def test_gemv_low_precision(lam, oracle, dtype_name, eps, n):
 @pytest.mark.parametrize("dtype_name", ["F32", "BF16"])
 def test_cg_low_precision(lam, oracle, dtype_name):
     """fp32 CG on a well-conditioned system: same iteration count as the fp32 oracle to +-max(3,5%),
-    solution within 1e-3 of the fp64 solve of the (rounded) system."""
+    solution within 1e-3 of the fp64 solve of the (rounded) system.  The fp32 oracle is PINNED: bit-identical to the
+    reference's own class instantiated with float on the `file_mode_f32` fixtures (tests/test_oracle_golden.py::
+    test_file_mode_float_bit_identical)."""
     n = 512
     rng = np.random.default_rng(21)
     q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
@@ -340,6 +342,42 @@ def test_cg_low_precision(lam, oracle, dtype_name):
     assert abs(st["num_iters"] - st_or["num_iters"]) <= max(3, 0.05 * st_or["num_iters"])
     x64 = np.linalg.solve(A_dev.astype(np.float64), b.astype(np.float64))
     assert np.linalg.norm(x - x64) / np.linalg.norm(x64) < 1e-3
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+def test_cg_file_mode_golden_f32(lam, oracle, golden, shards):
+    """The fp32 path against outputs of the REFERENCE's own solver class instantiated with float
+    (tests/golden `file_mode_f32`, produced by oracle/ref_float_harness.cpp -> ConjugateGradient_CPU_OMP<float>; the same
+    fixtures pin oracle_cg_solve_f32 bit for bit, tests/test_oracle_golden.py -- so the fp32 / bf16 comparisons with the
+    oracle elsewhere in this file are comparisons with a pinned oracle).  fp32 tolerances: the recursion runs at eps =
+    6e-8 with cond ~ 1e3, so a converged x agrees with the reference's to ~ cond x eps x a few; the iteration at which the
+    recursive residual crosses 1e-5 moves with the summation order (measured margins: profiles/r04_parity_margins_f32.txt)."""
+    seen = 0
+    for g in golden["file_mode_f32"]:
+        mpath, bpath = os.path.join(GOLDEN, g["name"] + ".f32.matrix.bin"), os.path.join(GOLDEN, g["name"] + ".f32.rhs.bin")
+        A = oracle.read_bin(mpath, dtype=np.float32).astype(np.float64)
+        b = oracle.read_bin(bpath, dtype=np.float32).reshape(-1).astype(np.float64)
+        x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin"), dtype=np.float32).reshape(-1).astype(np.float64)
+        with lam.Solver(lam.F32, n_shards=shards, device_ids=[0] * shards) as s:
+            assert s.load_matrix_from_file(mpath) and s.load_rhs_from_file(bpath)
+            conv = s.solve(g["max_iters"], g["tol"])
+            st, x = s.stats, s.solution().astype(np.float64)
+        assert conv == g["converged"], g["tag"]
+        err = np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)
+        print(f"f32 margin {g['tag']} shards={shards}: iters {st['num_iters']} (ref {g['iters_printed']}), |x-x_ref|/|x_ref| {err:.3e}, "
+              f"rel_err {st['rel_err']:.3e} (ref {g['rel_err_printed']:.3e})")
+        if g["converged"]:
+            assert abs(st["num_iters"] - g["iters_printed"]) <= max(3, 0.05 * g["iters_printed"]), (g["tag"], st)
+            assert st["rel_err"] < g["tol"]
+            assert np.linalg.norm(b - A @ x) / np.linalg.norm(b) <= 4 * g["tol"]
+            assert err <= 1e-3, (g["tag"], err)
+        else:
+            assert st["num_iters"] == g["max_iters"] + 1
+            # a fixed, small number of iterations: everything is well conditioned, rounding only
+            assert abs(st["rel_err"] / g["rel_err_printed"] - 1) < (1e-4 if g["max_iters"] <= 5 else 2e-2), (g["tag"], st)
+            assert err <= (1e-5 if g["max_iters"] <= 5 else 2e-3), (g["tag"], err)
+        seen += 1
+    assert seen >= 4
 
 
 # ------------------------------------------------------------------------------------------------

@@ -26,6 +26,10 @@ pytestmark = pytest.mark.gpu
 MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
 
 
+def ITER_GATE(ref_iters):      # noqa: N802  -- SURVEY 8c's iteration gate (profiles/r04_parity_margins.txt has the measured margins)
+    return max(2, 0.01 * ref_iters)
+
+
 def _env(mock, P, tmp_path, **extra):
     stats = os.path.join(str(tmp_path), "mock_stats.jsonl")
     # a kernel that waits for a peer must never share a hardware queue with the kernel it waits for
@@ -58,10 +62,17 @@ def _check_solution(out, P, n, mode):
     assert out["ranks_identical"], out          # every rank holds the same x, iteration count and residual
     assert out["converged"]
     assert len(set(out["collectives_enqueued"])) == 1, out
-    assert abs(out["iters"] - out["iters_single"]) <= max(3, 0.02 * out["iters_single"]), out
-    assert out["true_residual"] <= 2 * (1e-9 if mode == "tridiag" else 1e-10) + 1e-13
+    tol = 1e-9 if mode == "tridiag" else 1e-10
+    assert abs(out["iters"] - out["iters_single"]) <= ITER_GATE(out["iters_single"]), out
+    assert out["true_residual"] <= 2 * tol + 1e-13
     assert out["x_vs_single"] < (1e-5 if mode == "tridiag" else 1e-8), out   # tridiag(1,2,1): cond ~ N^2/2
     assert out["gemv_vs_single"] < 1e-13
+    if n <= 4096:
+        # tied to the reference algorithm itself (CPU oracle with the same number of emulated ranks, same system) and to a
+        # residual recomputed on the host -- not only to another run of the HIP path; file-mode gates
+        assert out["converged_oracle"] and abs(out["iters"] - out["iters_oracle"]) <= ITER_GATE(out["iters_oracle"]), out
+        assert out["residual_numpy"] <= 2 * tol + 1e-13 and abs(out["residual_numpy"] / out["true_residual"] - 1) < 1e-3, out
+        assert out["x_vs_oracle"] <= (1e-5 if mode == "tridiag" else 10 * tol), out
     base = n // P
     assert out["partition"] == [[q * base, base + (n % P if q == P - 1 else 0)] for q in range(P)]
 

@@ -36,6 +36,25 @@ def test_file_mode_bit_identical(oracle, golden):
         assert np.array_equal(x.view(np.uint64), x_ref.view(np.uint64)), g["tag"]  # bit-exact
 
 
+def test_file_mode_float_bit_identical(oracle, golden):
+    """The fp32 oracle (oracle_cg_solve_f32: the same generic body as the fp64 one) against the REFERENCE's own class
+    instantiated with float (oracle/ref_float_harness.cpp -> ConjugateGradient_CPU_OMP<float>, CPU_OMP.hpp:49-91; the
+    reference instantiates float for its GPU classes, ...CUDA_NCCL.cu:767): same iteration counts, printed residuals and
+    every bit of the solution vector.  This is what pins the oracle the fp32 / bf16 GPU parity tests compare with."""
+    assert len(golden["file_mode_f32"]) >= 4
+    for g in golden["file_mode_f32"]:
+        A = oracle.read_bin(os.path.join(GOLDEN, g["name"] + ".f32.matrix.bin"), dtype=np.float32)
+        b = oracle.read_bin(os.path.join(GOLDEN, g["name"] + ".f32.rhs.bin"), dtype=np.float32)
+        x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin"), dtype=np.float32).reshape(-1)
+        x, st = oracle.cg_solve(A, b, g["max_iters"], g["tol"], threads=1)
+        assert x.dtype == np.float32
+        assert st["converged"] == g["converged"], g["tag"]
+        printed_iters = st["num_iters"] if st["converged"] else g["max_iters"]
+        assert printed_iters == g["iters_printed"], (g["tag"], st)
+        assert _printed_equal(st["rel_err"], g["rel_err_printed"], 7), (g["tag"], st["rel_err"])
+        assert np.array_equal(x.view(np.uint32), x_ref.view(np.uint32)), g["tag"]  # bit-exact
+
+
 def test_solution_file_header_quirk(oracle, golden):
     """The reference writes `int num_cols=1` through sizeof(size_t) (CPU_OMP.hpp:208-210): the low
     32 bits of the cols word are 1; readers must mask."""
