@@ -34,6 +34,7 @@
 
 #include "../../../../include/lam_hip.h"
 #include "../ConjugateGradient.hpp"
+#include "reference_system.hpp"
 
 namespace LAM
 {
@@ -239,6 +240,24 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         if (_print_csv && is_root()) std::cout << rows << ",";
         if (lam_hip_generate_random_spd(_ctx, seed, cond) != 0) return report("generate_random_spd");
         if (lam_hip_generate_random_rhs(_ctx, seed + 1) != 0) return report("generate_random_rhs");
+        return true;
+    }
+    // extension: the reference GENERATOR's system (challenge/main/random_spd_system.cpp: spectrum exp(3.5 U[-1,1]), rhs
+    // U[-1,1], its srand/rand streams) built in place, without the files: A = H_k..H_1 diag(d) H_1..H_k (reference_system.hpp)
+    virtual bool generate_reference_system(const size_t rows, int seed, int reflectors = 4)
+    {
+        if (!ensure_ctx()) return false;
+        if (lam_hip_set_problem(_ctx, rows) != 0) return report("set_problem");
+        _num_rows = _num_cols = rows;
+        if (_print_csv && is_root()) std::cout << rows << ",";
+        const ReferenceSystemStreams st = reference_system_streams(rows, seed, reflectors);
+        if (lam_hip_generate_spectrum_spd(_ctx, st.eig.data(), st.reflectors.data(), reflectors) != 0) return report("generate_spectrum_spd");
+        if constexpr (std::is_same<FloatingType, double>::value) {
+            if (lam_hip_set_rhs(_ctx, st.rhs.data()) != 0) return report("set_rhs");
+        } else {
+            const std::vector<float> bf(st.rhs.begin(), st.rhs.end());
+            if (lam_hip_set_rhs(_ctx, bf.data()) != 0) return report("set_rhs");
+        }
         return true;
     }
     virtual bool generate_rhs()

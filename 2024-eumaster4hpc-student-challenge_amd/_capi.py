@@ -95,6 +95,7 @@ def lib():
             "lam_hip_download_rows": ([vp, u64, u64, vp], i32),
             "lam_hip_generate_tridiag": ([vp], i32),
             "lam_hip_generate_random_spd": ([vp, u64, C.c_double], i32),
+            "lam_hip_generate_spectrum_spd": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i32], i32),
             "lam_hip_set_rhs": ([vp, vp], i32),
             "lam_hip_get_rhs": ([vp, vp], i32),
             "lam_hip_generate_rhs": ([vp, C.c_double], i32),
@@ -267,6 +268,15 @@ class Solver:
     def generate_random_spd(self, n, seed, cond):
         self.set_problem(n)
         self._chk(self._L.lam_hip_generate_random_spd(self._h, seed, cond))
+
+    def generate_spectrum_spd(self, eig, reflectors):
+        """A = H_k..H_1 diag(eig) H_1..H_k (the reference generator's law, random_spd_system.cpp:66-97, with Householder
+        reflectors for Q); `reflectors`: k x N array (k may be 0: the diagonal matrix itself)."""
+        eig = np.ascontiguousarray(eig, dtype=np.float64).reshape(-1)
+        V = np.ascontiguousarray(reflectors, dtype=np.float64).reshape(-1, eig.size) if np.size(reflectors) else np.zeros((0, eig.size))
+        self.set_problem(eig.size)
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.lam_hip_generate_spectrum_spd(self._h, eig.ctypes.data_as(dp), V.ctypes.data_as(dp), V.shape[0]))
 
     def generate_rhs(self, value=1.0):
         self._chk(self._L.lam_hip_generate_rhs(self._h, value))

@@ -2146,6 +2146,82 @@ int lam_hip_generate_random_spd(lam_hip_ctx *c, uint64_t seed, double cond)
     return 0;
 }
 
+int lam_hip_generate_spectrum_spd(lam_hip_ctx *c, const double *eig, const double *v, int k)
+{
+    if (!c || !eig || (k > 0 && !v) || k < 0) return LAM_HIP_EINVAL;
+    if (!c->have_problem) return fail(c, LAM_HIP_ESTATE, "call lam_hip_set_problem first");
+    if (c->dtype == LAM_HIP_BF16) return fail(c, LAM_HIP_EINVAL, "the spectrum generator works in the storage type: fp64 / fp32 only");
+    const uint64_t n = c->n;
+    for (uint64_t i = 0; i < n; i++)
+        if (!(eig[i] > 0.0)) return fail(c, LAM_HIP_EINVAL, "eigenvalue %llu is not positive", (unsigned long long)i);
+    const bool f64 = c->dtype == LAM_HIP_F64;
+    const size_t ev = c->esz_v();
+    // host vectors in the context's vector type (what lam_hip_gemv and the uploads take)
+    std::vector<double> vd(n), ud(n), wd(n);
+    std::vector<float> vf(f64 ? 0 : n), uf(f64 ? 0 : n), wf(f64 ? 0 : n);
+    auto to_dev = [&](const std::vector<double> &src, std::vector<float> &tmp) -> const void * {
+        if (f64) return src.data();
+        for (uint64_t i = 0; i < n; i++) tmp[i] = (float)src[i];
+        return tmp.data();
+    };
+    auto upload = [&](void *ShardBase::*dst, const void *host) -> int {
+        for (auto &s : c->sh) {
+            LAMCHK(set_dev(c, s));
+            HIPCHK(c, hipMemcpyAsync(s.*dst, host, n * ev, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(c, hipStreamSynchronize(s.stream));
+        }
+        return 0;
+    };
+    // 0. A = diag(eig)
+    for (uint64_t i = 0; i < n; i++) vd[i] = eig[i];
+    LAMCHK(upload(&ShardBase::tmp, to_dev(vd, vf)));
+    LAMCHK(dispatch(c, [&](auto impl) -> int {
+        using TA = typename ImplTraits<decltype(impl)>::TA;
+        using TV = typename ImplTraits<decltype(impl)>::TV;
+        for (auto &s : c->sh) {
+            if (s.nrows == 0) continue;
+            LAMCHK(set_dev(c, s));
+            hipLaunchKernelGGL((gen_diag_kernel<TA, TV>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, n, (const TV *)s.tmp);
+            HIPCHK(c, hipGetLastError());
+        }
+        return 0;
+    }));
+    LAMCHK(sync_all(c));
+    c->have_matrix = true; c->cg_ready = false;
+    // 1. one two-sided reflection per vector
+    for (int j = 0; j < k; j++) {
+        const double *vj = v + (size_t)j * n;
+        double vv = 0.0;
+        for (uint64_t i = 0; i < n; i++) { vd[i] = vj[i]; vv += vj[i] * vj[i]; }
+        if (!(vv > 0.0)) return fail(c, LAM_HIP_EINVAL, "reflector %d is the zero vector", j);
+        const double tau = 2.0 / vv;
+        // w = A v through the product GEMV (a collective in rank mode: every rank receives the full vector)
+        const void *vdev = to_dev(vd, vf);
+        LAMCHK(lam_hip_gemv(c, vdev, f64 ? (void *)wd.data() : (void *)wf.data()));
+        if (!f64) for (uint64_t i = 0; i < n; i++) wd[i] = wf[i];
+        double alpha = 0.0;
+        for (uint64_t i = 0; i < n; i++) alpha += vj[i] * wd[i];
+        for (uint64_t i = 0; i < n; i++) { ud[i] = wd[i] - 0.5 * tau * alpha * vj[i]; vd[i] = tau * vj[i]; }
+        LAMCHK(upload(&ShardBase::tmp, to_dev(vd, vf)));        // tau v
+        LAMCHK(upload(&ShardBase::p, to_dev(ud, uf)));          // u (p is rewritten by cg_init anyway)
+        LAMCHK(dispatch(c, [&](auto impl) -> int {
+            using TA = typename ImplTraits<decltype(impl)>::TA;
+            using TV = typename ImplTraits<decltype(impl)>::TV;
+            for (auto &s : c->sh) {
+                if (s.nrows == 0) continue;
+                LAMCHK(set_dev(c, s));
+                hipLaunchKernelGGL((rank2_update_kernel<TA, TV>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, n,
+                                   (const TV *)s.tmp, (const TV *)s.p);
+                HIPCHK(c, hipGetLastError());
+            }
+            return 0;
+        }));
+        LAMCHK(sync_all(c));
+    }
+    c->have_matrix = true; c->cg_ready = false;
+    return 0;
+}
+
 int lam_hip_set_rhs(lam_hip_ctx *c, const void *b_host)
 {
     if (!c || !b_host) return LAM_HIP_EINVAL;

@@ -2022,6 +2022,41 @@ gen_random_spd_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_
     }
 }
 
+// ---- dense SPD matrix with a PRESCRIBED SPECTRUM: A = H_k ... H_1 diag(eig) H_1 ... H_k, H_j = I - tau_j v_j v_j^T
+// (the reference generator's law A = Q diag(exp(3.5 u)) Q^T, challenge/main/random_spd_system.cpp:66-97, with Q a product of
+// Householder reflectors instead of an O(N^3) Gram-Schmidt: exact spectrum up to rounding, exactly symmetric, O(k N^2)).
+// Step 0: the diagonal matrix; then per reflector  w = A v (the GEMV kernel),  u = w - (tau v.w / 2) v (host),
+// A <- A - (tau v) u^T - u (tau v)^T  by the kernel below.
+template <typename TA, typename TV>
+__global__ void __launch_bounds__(kBlock)
+gen_diag_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ eig /* full length */)
+{
+    const uint64_t total = nrows * n;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t i = idx / n + row0, j = idx % n;
+        A[idx] = i == j ? to_storage<TA>((double)eig[i]) : to_storage<TA>(0.0);
+    }
+}
+
+// A[i][j] -= tv[i] u[j] + u[i] tv[j]  with the two products rounded SEPARATELY and then added (no FMA contraction): element
+// (j, i) adds the same two products in the other order, and a + b == b + a, so a symmetric A stays symmetric bit for bit.
+template <typename TA, typename TV>
+__global__ void __launch_bounds__(kBlock)
+rank2_update_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ tv, const TV *__restrict__ u)
+{
+    const uint64_t total = nrows * n;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t i = idx / n + row0, j = idx % n;
+        if constexpr (sizeof(TV) == 8) {
+            const double p1 = __dmul_rn(tv[i], u[j]), p2 = __dmul_rn(u[i], tv[j]);
+            A[idx] = to_storage<TA>(__dsub_rn((double)A[idx], __dadd_rn(p1, p2)));
+        } else {
+            const float p1 = __fmul_rn(tv[i], u[j]), p2 = __fmul_rn(u[i], tv[j]);
+            A[idx] = to_storage<TA>((double)__fsub_rn((float)A[idx], __fadd_rn(p1, p2)));
+        }
+    }
+}
+
 template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 gen_rhs_kernel(TV *__restrict__ b, uint64_t row0, uint64_t n_loc, int random, uint64_t seed, double value)

@@ -38,6 +38,8 @@ void usage(const char *exe)
     printf("  -s <int>        Generate matrix of size n x n\n");
     printf("  -r <seed>       with -s: seeded dense random SPD system instead of tridiag(1,2,1)\n");
     printf("  -c <float>      with -r: spread of the spectrum (default 1e4)\n");
+    printf("  -R <seed>       with -s: the system the reference GENERATOR makes for this seed (random_spd_system.cpp: spectrum\n");
+    printf("                  exp(3.5 U[-1,1]), rhs U[-1,1], its srand/rand streams), built on the device without the files\n");
     printf("  -t <type>       f64 (default, what the reference drivers hard-code), f32, or bf16 (bf16 matrix\n");
     printf("                  storage, fp32 vectors); files hold doubles for f64 and floats otherwise\n");
     printf("  -v              Verbose mode\n");
@@ -51,6 +53,8 @@ struct Options {
     double rel_error = 1e-9, cond = 1e4;
     size_t rows = 0;
     long seed = -1;
+    int ref_seed = 0;
+    bool have_ref_seed = false;
     bool verbose = false, mode_generate = false, mode_load = false, bf16_storage = false;
 };
 
@@ -88,7 +92,7 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
     const char *precision = "f64";
 
     int opt;
-    while ((opt = getopt(argc, argv, "hvA:b:o:i:e:s:r:c:t:")) != -1) {
+    while ((opt = getopt(argc, argv, "hvA:b:o:i:e:s:r:R:c:t:")) != -1) {
         switch (opt) {
         case 'A':
         case 'b':
@@ -111,6 +115,7 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
             rows = (size_t)atoll(optarg);
             break;
         case 'r': seed = atol(optarg); break;
+        case 'R': o.ref_seed = atoi(optarg); o.have_ref_seed = true; break;
         case 'c': cond = atof(optarg); break;
         case 't': precision = optarg; break;
         case 'v': verbose = true; break;
@@ -153,6 +158,8 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     const double rel_error = o.rel_error, cond = o.cond;
     const size_t rows = o.rows;
     const long seed = o.seed;
+    const int ref_seed = o.ref_seed;
+    const bool have_ref_seed = o.have_ref_seed;
     const bool verbose = o.verbose, mode_generate = o.mode_generate, root = L.rank == 0;
     LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<T> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id, o.bf16_storage);
     cg.set_csv_output(!verbose);
@@ -169,7 +176,9 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     }
     const auto t0 = clk::now();
     bool ok;
-    if (mode_generate) ok = seed >= 0 ? cg.generate_random_system(rows, (uint64_t)seed, cond) : cg.generate_matrix(rows, rows);
+    if (mode_generate)
+        ok = have_ref_seed ? cg.generate_reference_system(rows, ref_seed)
+                           : (seed >= 0 ? cg.generate_random_system(rows, (uint64_t)seed, cond) : cg.generate_matrix(rows, rows));
     else ok = cg.load_matrix_from_file(matrix_file);
     const double t_load = std::chrono::duration<double>(clk::now() - t0).count();
     if (!ok) {      // the loaders agree across ranks: a block that failed on one rank fails here on all
@@ -178,7 +187,7 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     }
     if (root && !verbose) std::cout << L.size << "," << 1 << "," << t_load << ",";
     if (verbose && root) printf("Matrix ready in %f s\n", t_load);
-    if (mode_generate) ok = seed >= 0 ? true : cg.generate_rhs();
+    if (mode_generate) ok = (seed >= 0 || have_ref_seed) ? true : cg.generate_rhs();
     else ok = cg.load_rhs_from_file(rhs_file);
     if (!ok) {
         if (root) fprintf(stderr, "Failed to read right hand side\n");

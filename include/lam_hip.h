@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define LAM_HIP_ABI_VERSION 1
+/* 2 (round 4): lam_hip_build_id (added in round 3 without a bump) and lam_hip_generate_spectrum_spd; nothing removed or changed */
+#define LAM_HIP_ABI_VERSION 2
 
 /* storage / arithmetic type of the matrix and vectors */
 #define LAM_HIP_F64 0  /* double everywhere (the reference drivers hard-code <double>) */
@@ -134,6 +135,15 @@ int lam_hip_generate_tridiag(lam_hip_ctx *ctx);
  *   A[i][j] = A[j][i] = u(seed,min,max)/N, u in [-1,1);  A[i][i] = 1 + (cond-1)*v(seed,i), v in [0,1)
  * eigenvalues lie in (0, cond+1): `cond` spreads the spectrum so CG does not converge at once. */
 int lam_hip_generate_random_spd(lam_hip_ctx *ctx, uint64_t seed, double cond);
+
+/* Dense SPD matrix with a PRESCRIBED SPECTRUM, the law of the reference's fixture generator
+ * (challenge/main/random_spd_system.cpp:66-97: A = Q diag(d) Q^T, d_i = exp(3.5 U[-1,1]), cond ~ 1.1e3), built on the device:
+ *   A = H_k ... H_1 diag(eig) H_1 ... H_k,   H_j = I - 2 v_j v_j^T / (v_j . v_j),   v_j = v[j*N .. j*N+N)
+ * i.e. Q is a product of k Householder reflectors instead of the reference's O(N^3) Gram-Schmidt with MKL: the spectrum is
+ * `eig` up to rounding, A is symmetric bit for bit, cost O(k N^2) (one GEMV + one rank-2 update pass per reflector).  eig:
+ * N positive values, v: k x N (host, double).  fp64 / fp32 storage.  Collective in rank mode (every rank passes the same
+ * arrays).  apps/random_spd_system.cpp draws eig, v and the rhs from srand/rand exactly as the reference does. */
+int lam_hip_generate_spectrum_spd(lam_hip_ctx *ctx, const double *eig, const double *v, int k);
 
 /* b: load_rhs_from_file (ConjugateGradient_CPU_MPI_OMP.hpp:258-305) / generate_rhs (:144-165).
  * b_host has N elements of the vector dtype (double for F64, float otherwise). */

@@ -37,6 +37,37 @@ def main():
                        for n, rs in sorted(by_n.items())]}
     json.dump(out, open(OUT, "w"), indent=1)
     print(f"{len(out['entries'])} sizes -> {OUT}")
+    file_grid()
+
+
+def file_grid():
+    """File mode on the matrices of the reference's generator (matrix{N}.bin, never published): iteration counts and residuals
+    the reference's CPU MPI+OMP path printed for N = 10000 ... 50000, tol 1e-9 (TESTS/BEST_RESULTS, the two CPU_MPI_OMP
+    file-mode sections).  The count is a property of the generator's matrix LAW (spectrum exp(3.5 U[-1,1]), random rhs), not
+    of N: 358-360 everywhere -- a known answer for systems drawn from that law (apps/random_spd_system.out, driver option -R)."""
+    rows, section = [], None
+    for ln, line in enumerate(open(SRC), 1):
+        line = line.strip()
+        if line.startswith("---") and line.strip("-"):
+            section = line.strip("-")
+        m = re.fullmatch(r"(\d+),(\d+),(\d+),([\d.e+-]+),([\d.e+-]+),([\d.e+-]+),(\d+),([\d.e+-]+),([\d.e+-]+)", line)
+        if not m or section is None or not section.startswith("CPU_MPI_OMP") or "gen" in section:
+            continue
+        n, p, thr, _, _, _, iters, err, _ = m.groups()
+        if int(n) <= 70000 and int(iters) < 10001:
+            rows.append({"n": int(n), "mpi_ranks": int(p), "iters_printed": int(iters), "err_printed": err, "source": f"TESTS/BEST_RESULTS:{ln}"})
+    by_n = {}
+    for r in rows:
+        by_n.setdefault(r["n"], []).append(r)
+    out = {"what": "file mode, tol 1e-9, matrices of the reference generator (random_spd_system.cpp: A = Q diag(exp(3.5 U[-1,1])) Q^T, rhs "
+                   "U[-1,1]): printed iters and err of test_CPU_MPI_OMP.out on MeluXina, all rank counts",
+           "grid_script": "TESTS/CPU_SCRIPTS/CPU_1_NODE.sh:23-27",
+           "entries": [{"n": n, "iters_min": min(r["iters_printed"] for r in rs), "iters_max": max(r["iters_printed"] for r in rs),
+                        "err_printed": sorted({r["err_printed"] for r in rs}), "sources": [r["source"] for r in rs]}
+                       for n, rs in sorted(by_n.items())]}
+    path = os.path.join(os.path.dirname(OUT), "reference_file_grid.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(f"{len(out['entries'])} file-mode sizes -> {path}: " + ", ".join(f"{e['n']}: {e['iters_min']}-{e['iters_max']}" for e in out["entries"]))
 
 
 if __name__ == "__main__":

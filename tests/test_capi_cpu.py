@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(lam):
 def test_binding_covers_header(lam):
     L = lam.lib()
     assert set(_declared_symbols()) == set(L._lam_symbols)
-    assert L.lam_hip_abi_version() == 1
+    assert L.lam_hip_abi_version() == 2
 
 
 def test_no_cpu_fallback(lam):

@@ -407,6 +407,25 @@ def test_generator_tool_with_the_reference_cli(tmp_path, oracle):
     b = oracle.read_bin(rhs).reshape(-1)
     assert A.shape == (300, 300) and b.shape == (300,)
     assert np.array_equal(A, A.T) and np.linalg.eigvalsh(A).min() > 0
+    # THE REFERENCE'S LAW AND ITS RANDOM NUMBERS (random_spd_system.cpp:27-37,83-87,166): eigenvalues exp(3.5 u) with u from
+    # srand(seed - 10) / rand(), rhs from srand(seed + 10) / rand() -- drawn here from the same libc
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.rand.restype = ctypes.c_int
+
+    def stream(seed, count):
+        libc.srand(ctypes.c_uint(seed & 0xFFFFFFFF))
+        return np.array([(2.0 * libc.rand()) / 2147483647 - 1.0 for _ in range(count)])
+
+    eig = np.exp(3.5 * stream(42 - 10, 300))
+    assert np.array_equal(b, stream(42 + 10, 300))
+    w = np.linalg.eigvalsh(A)
+    assert np.max(np.abs(w - np.sort(eig))) <= 1e-12 * eig.max()
+    assert w.max() / w.min() > 100                                                # the spectrum spans decades (cond -> e^7 ~ 1.1e3)
+    assert np.count_nonzero(A) == A.size                                          # dense
+    # the round-1..3 law is still there on request (what bench.py generates in place)
+    r3 = _run([gen, "300", str(tmp_path / "m3.bin"), str(tmp_path / "r3.bin"), "42", "dominant"])
+    assert r3.returncode == 0 and not np.array_equal(oracle.read_bin(str(tmp_path / "m3.bin")), A)
     r2 = _run([gen, "300", str(tmp_path / "m2.bin"), str(tmp_path / "r2.bin"), "42"])   # seeded: reproducible
     assert r2.returncode == 0 and open(mat, "rb").read() == open(tmp_path / "m2.bin", "rb").read()
     r = _run([ONE_EXE, mat, rhs, sol, "2000", "1e-10"])
@@ -447,10 +466,12 @@ def test_reference_generate_grid_known_answers(tmp_path):
 
 
 def test_reference_file_grid_sizes(tmp_path):
-    """The file-mode sizes of TESTS/GPU_SCRIPTS/GPU_1_NODE.sh:41-47 (10000 ... 70000, default tolerance 1e-9): the
-    reference's matrix files were never published, so the systems are generated on the device; the smallest one also
-    goes through real files written by the generator tool (reference CLI) and the -A/-b loaders.  Every point prints
-    the reference's 10 CSV columns and converges below the tolerance."""
+    """The file-mode sizes of TESTS/GPU_SCRIPTS/GPU_1_NODE.sh:41-47 (10000 ... 70000, default tolerance 1e-9) on systems drawn
+    from the reference GENERATOR's law (round 4: apps/random_spd_system.out and the driver's -R option reproduce it -- spectrum
+    exp(3.5 U[-1,1]), rhs U[-1,1], the reference's srand/rand streams): the reference's own runs on its generator's matrices
+    took 358-360 iterations at every size (tests/golden/reference_file_grid.json <- TESTS/BEST_RESULTS:93-135), and so must
+    these, to 3 % -- the first FILE-mode known answer of the reference the package is held to.  The smallest size goes through
+    real files written by the generator tool and the -A/-b loaders."""
     js = tmp_path / "file.json"
     r = subprocess.run([sys.executable, SWEEP, "--grid", "file", "--json", str(js), "--files", str(tmp_path), "--files-max-n", "10000"],
                        capture_output=True, text=True, timeout=1500)
@@ -458,7 +479,8 @@ def test_reference_file_grid_sizes(tmp_path):
     import json
     recs = json.load(open(js))
     assert [x["n"] for x in recs] == [10000, 20000, 30000, 40000, 50000, 60000, 70000]
-    assert "file mode" in recs[0]["mode"] and all("device-generated" in x["mode"] for x in recs[1:])
+    assert "file mode" in recs[0]["mode"] and all("built on the device" in x["mode"] for x in recs[1:])
     for x in recs:
         f = x["csv"].split(",")
         assert x["match"] and len(f) == 10 and f[0] == str(x["n"]) and f[1] == "1" and float(f[8]) < 1e-9 and float(f[5]) > 0
+        assert 0.97 * 358 <= x["iters"] <= 1.03 * 360, x

@@ -119,7 +119,26 @@ def test_heat_cg_file_mode_config5(lam, oracle, tmp_path):
     assert true_res <= 2e-9
     x_or, st_or = oracle.cg_solve(np.asarray(A), b, 10000, 1e-9, threads=16)
     assert st_or["converged"]
+    # iteration gate: max(3, 2 %) -- what the HIP path measures against the reference's own fixtures (-3 ... 0 over 45
+    # fixture x topology runs, profiles/r04_parity_margins.txt; SURVEY 8c's max(2, 1 %) would fail the 181-vs-184 case)
     assert abs(int(f[7]) - st_or["num_iters"]) <= max(3, 0.02 * st_or["num_iters"])
-    assert abs(float(f[8]) - st_or["rel_err"]) < 1e-9                     # residual match vs CPU to 1e-9
-    assert np.linalg.norm(x - x_or) / np.linalg.norm(x_or) < 1e-6
+    # solution: both x solve the system only to their residuals, x - x_or = A^-1 (r_or - r), so
+    # ||x - x_or|| <= (||r|| + ||r_or||) / lambda_min -- rigorous; lambda_min of the 5-point Laplacian on the m x m interior
+    # grid is 4 - 4 cos(pi / (m + 1)) (= 1.186e-3 at m = 128: cond = 6.7e3)
+    lam_min = 4.0 - 4.0 * np.cos(np.pi / (nx - 1))
+    bound = (np.linalg.norm(b - A @ x) + np.linalg.norm(b - A @ x_or)) / lam_min
+    assert np.linalg.norm(x - x_or) <= 1.01 * bound
+    assert np.linalg.norm(x - x_or) / np.linalg.norm(x_or) < 1e-6          # what that bound evaluates to here, rounded up
+    # "residual match vs CPU" (BASELINE configs[4]): the RECURSIVE residual after a FIXED number of iterations, HIP against
+    # the oracle on the same files -- a comparison of two numbers of size 1e-2 ... 1e-5, not of two numbers that are both
+    # already below the tolerance
+    with lam.Solver(lam.F64) as s:
+        assert s.load_matrix_from_file(m) and s.load_rhs_from_file(rhs)
+        for k in (100, 200):
+            s.solve(k, 1e-30)
+            _, st_k = oracle.cg_solve(np.asarray(A), b, k, 1e-30, threads=16)
+            assert s.stats["num_iters"] == st_k["num_iters"] == k + 1
+            rel = abs(s.stats["rel_err"] / st_k["rel_err"] - 1)
+            print(f"heat n={n}: recursive residual after {k} iterations: HIP {s.stats['rel_err']:.15e} oracle {st_k['rel_err']:.15e} (relative difference {rel:.2e})")
+            assert rel < 1e-9, (k, s.stats["rel_err"], st_k["rel_err"])
     assert 0.0 < x.min() and x.max() < 100.0                              # discrete maximum principle
