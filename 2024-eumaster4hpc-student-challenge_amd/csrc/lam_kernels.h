@@ -2044,16 +2044,17 @@ template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)
 rank2_update_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ tv, const TV *__restrict__ u)
 {
+#pragma clang fp contract(off)      // plain operators under contract(off): nothing here may be fused into an fma -- fma(tv_i, u_j,
+                                    // u_i tv_j) rounds one product and not the other, and (i, j) != (j, i) in the last bit.  (The
+                                    // __dmul_rn / __dadd_rn intrinsics do NOT help: they are inline functions of the HIP headers
+                                    // with the default contract(fast), and came out as v_fmac_f64.)
     const uint64_t total = nrows * n;
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint64_t i = idx / n + row0, j = idx % n;
-        if constexpr (sizeof(TV) == 8) {
-            const double p1 = __dmul_rn(tv[i], u[j]), p2 = __dmul_rn(u[i], tv[j]);
-            A[idx] = to_storage<TA>(__dsub_rn((double)A[idx], __dadd_rn(p1, p2)));
-        } else {
-            const float p1 = __fmul_rn(tv[i], u[j]), p2 = __fmul_rn(u[i], tv[j]);
-            A[idx] = to_storage<TA>((double)__fsub_rn((float)A[idx], __fadd_rn(p1, p2)));
-        }
+        const TV p1 = tv[i] * u[j];
+        const TV p2 = u[i] * tv[j];
+        const TV s12 = p1 + p2;
+        A[idx] = to_storage<TA>((double)((TV)A[idx] - s12));
     }
 }
 
