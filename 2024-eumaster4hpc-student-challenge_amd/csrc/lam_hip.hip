@@ -2473,6 +2473,16 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
                                      "the iteration state is no longer valid", c->rank, code >= 2 && code <= 5 ? what[code] : "?", code,
                     c->direct_err[1], c->direct_err[4], c->direct_err[2], c->direct_err[5], c->direct_err[3]);
     }
+    if (c->cg_direct && c->rank_mode && c->nranks > 1 && enq > 0) {
+        // Direct exchange, one process per GPU: this rank's last iteration is complete once it has the peers' r.r, while
+        // those peers may still be storing their p slices into THIS rank's replica (nobody waits for them any more).  A
+        // caller that destroys the context or sets a new problem right after this call would free or unmap memory a peer
+        // kernel is still writing.  One stream-ordered agreement closes the call: every rank's contribution is
+        // enqueued behind its last iteration, so when it completes here, every peer's stores have been issued and drained.
+        // (Only on the success path: after an expired wait every rank is already on its way out with an error.)
+        int all = 0;
+        LAMCHK(lam_hip_all_ok(c, 1, &all));
+    }
     // harvest the GEMV timings still in the ring
     for (int j = 0; j < kLag; j++) harvest_gemv_time(s0, j, &gemv_ms, &gemv_samples);
     LAMCHK(set_dev(c, s0));

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--cond", type=float, default=200.0)
     ap.add_argument("--dtype", choices=["f64", "f32", "bf16"], default="f64")
     ap.add_argument("--no-single", action="store_true", help="skip the single-shard comparison run")
+    ap.add_argument("--quick-destroy", type=int, default=0, help="K > 0: cg_init + cg_iterate(K) and destroy the context at once, "
+                    "nothing collective in between (the direct exchange must have quiesced by itself); prints {ok: true}")
     a = ap.parse_args()
     P, n, mode = a.P, a.n, a.mode
     if mode == "file":
@@ -72,6 +74,11 @@ def main():
                 if a.finalize != 1:
                     s.set_option("finalize", a.finalize)     # 0 exists in the tuning build only
                 s.set_option("fuse_update", a.fuse)
+                if a.quick_destroy > 0:
+                    s.cg_init()
+                    st = s.cg_iterate(a.quick_destroy, 0.0)
+                    out[r] = dict(iters=st["num_iters"], err=st["rel_err"], eff=s.get_option("exchange_effective"))
+                    return                                   # leaves the `with`: lam_hip_destroy right behind the last iteration
                 if a.chunk > 0:
                     s.cg_init()
                     done, conv, calls = 0, False, 0
@@ -98,8 +105,12 @@ def main():
         t.join(300)
     if errs or any(o is None for o in out):
         print(json.dumps({"error": errs or "a rank did not finish",
-                          "ncoll": [o["ncoll"] if o else None for o in out]}))
+                          "ncoll": [o.get("ncoll") if o else None for o in out]}))
         sys.exit(1)
+    if a.quick_destroy > 0:
+        print(json.dumps({"ok": True, "iters": [o["iters"] for o in out], "rel_err": [o["err"] for o in out],
+                          "exchange_effective": [o["eff"] for o in out]}))
+        return
     res = {
         "P": P, "n": n, "iters": out[0]["iters"], "converged": bool(out[0]["conv"]), "true_residual": out[0]["res"],
         "rel_err": out[0]["err"], "partition": [list(o["part"]) for o in out],

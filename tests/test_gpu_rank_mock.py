@@ -267,6 +267,19 @@ def test_direct_exchange_solve_checks_itself_and_falls_back(mock_async, tmp_path
     assert out["direct_fallbacks"] == [0, 0, 0, 0] and out["exchange_effective"] == [2, 2, 2, 2]
 
 
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_direct_exchange_context_can_be_destroyed_right_after_iterating(mock_async, tmp_path, overlap):
+    """on the direct exchange a rank's last iteration is complete once it has the peers' r.r, while those peers
+    may still be storing p slices into its replica.  lam_hip_cg_iterate therefore ends with one stream-ordered agreement, so a
+    caller may destroy the context (or set a new problem) the moment it returns -- here 4 ranks as threads of one process
+    (plain pointers into each other's allocations: a late store would hit freed memory), three times over."""
+    for _ in range(3):
+        r, out, lines = _run(mock_async, tmp_path, 4, 4096, "spd", "--exchange", 2, "--overlap", overlap, "--quick-destroy", 25)
+        assert out.get("ok") and out["exchange_effective"] == [2] * 4 and len(set(out["rel_err"])) == 1 and out["iters"] == [26] * 4, out
+        _check_mock_stats(lines, 4)
+        os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
+
+
 # ---- multi-process: the driver's exact torchrun command ------------------------------------------------
 def _bench_torchrun(mock, nproc, tmp_path, extra_env=None):
     env = dict(os.environ, LD_PRELOAD=mock, GPU_MAX_HW_QUEUES="8", MOCK_RCCL_STATS_FILE=os.path.join(str(tmp_path), "st.jsonl"))
