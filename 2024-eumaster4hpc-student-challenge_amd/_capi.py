@@ -40,8 +40,7 @@ def lib_path():
 
 def build(force=False):
     """Compile liblam_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_HERE, "csrc", f) for f in ("lam_hip.hip", "lam_kernels.h")]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "lam_hip.h"))
+    srcs = _source_files()
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         r = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
@@ -53,14 +52,20 @@ def build(force=False):
 _lib = None
 
 
+def _source_files():
+    """csrc/lam_hip.hip, every csrc/*.h it includes (sorted, as the Makefile's $(sort $(wildcard ...))), include/lam_hip.h."""
+    import glob
+    return ([os.path.join(_HERE, "csrc", "lam_hip.hip")] + sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+            + [os.path.join(os.path.dirname(_HERE), "include", "lam_hip.h")])
+
+
 def source_id():
     """sha256 prefix of the sources the library is built from (same recipe as the Makefile's SRC_ID), or None when the
     sources are not next to the package."""
     import hashlib
     h = hashlib.sha256()
     try:
-        for f in (os.path.join(_HERE, "csrc", "lam_hip.hip"), os.path.join(_HERE, "csrc", "lam_kernels.h"),
-                  os.path.join(os.path.dirname(_HERE), "include", "lam_hip.h")):
+        for f in _source_files():
             with open(f, "rb") as fh:
                 h.update(fh.read())
     except OSError:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Registers / LDS / occupancy of every kernel in csrc/lam_hip.hip as the compiler reports them
+"""Registers / LDS / occupancy of every kernel of the translation unit csrc/lam_hip.hip (+ csrc/lam_*.h) as the compiler reports them
 (-Rpass-analysis=kernel-resource-usage; cross-compiles, no GPU needed).
     usage: kernel_resources.py [substring ...] [--tuning]"""
 import os
