@@ -303,7 +303,10 @@ int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
         if (++polls <= 64u) { __builtin_ia32_pause(); continue; }
         const double t = now_s();
         if (t_query == 0.0) t_query = t;
-        if (t - t_query > 2e-3) {                       // liveness: look at the stream every 2 ms of waiting
+        // Liveness: look at the stream only after 0.25 s of waiting for ONE iteration (a fault, a lost device).  Not more often:
+        // a hipStreamQuery on a busy stream makes a helper thread of the runtime wait ACTIVELY for the stream's outstanding
+        // signal -- called every 2 ms it kept a second core busy for the whole solve at N=65536 (tools/thread_cpu.py).
+        if (t - t_query > 0.25) {
             t_query = t;
             const hipError_t e = hipStreamQuery(s0.stream);
             if (e == hipSuccess) {
