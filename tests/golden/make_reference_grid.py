@@ -35,8 +35,18 @@ def main():
            "entries": [{"n": n, "max_iters": 15, "iters_printed": rs[0]["iters_printed"], "err_printed": rs[0]["err_printed"],
                         "sources": [r["source"] for r in rs], "rank_counts": sorted({r["mpi_ranks"] for r in rs})}
                        for n, rs in sorted(by_n.items())]}
+    # one more generate-mode known answer, from the GPU weak-scaling series: `-s 80000 -i 1000` on 64 GPUs printed 1001, 1.25e-06
+    # (= 1 / (1000 sqrt(8 * 80000)): the closed form of tridiag(1,2,1), b = 1)
+    extra = []
+    for ln, line in enumerate(open("/root/reference/TESTS/results/WEAK_SCALABILITY_GPU_MPI.txt"), 1):
+        m = re.fullmatch(r"(\d+),(\d+),(\d+),([\d.e+-]+),([\d.e+-]+),([\d.e+-]+),(\d+),([\d.e+-]+),([\d.e+-]+)", line.strip())
+        if m and m.group(7) == "1001":
+            extra.append({"n": int(m.group(1)), "max_iters": 1000, "iters_printed": 1001, "err_printed": m.group(8),
+                          "sources": [f"TESTS/results/WEAK_SCALABILITY_GPU_MPI.txt:{ln}"], "rank_counts": [int(m.group(2))]})
+    assert len(extra) == 1, extra
+    out["entries_extra"] = extra
     json.dump(out, open(OUT, "w"), indent=1)
-    print(f"{len(out['entries'])} sizes -> {OUT}")
+    print(f"{len(out['entries'])} sizes (+{len(extra)} extra) -> {OUT}")
     file_grid()
 
 
