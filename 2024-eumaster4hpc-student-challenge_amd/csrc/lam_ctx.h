@@ -77,6 +77,12 @@ struct lam_hip_ctx {
     ncclComm_t comm = nullptr;
     double t_comm_init = 0.0;
     uint64_t n = 0;
+    uint64_t lda = 0;              // row pitch of A in ELEMENTS: n rounded up so that a row is a whole number of 4-KiB pages (of
+                                   // 16-byte vectors when a row is shorter than a page); the padding is zero.  Every row then
+                                   // starts page-aligned -- round decimal sizes (N = 10000 ... 70000, the reference's grid) stream
+                                   // 0.5-1.5 % faster than with rows packed back to back (profiles/r04_size_sweep_align.txt) --
+                                   // and the 16-byte-vector GEMV kernels serve ANY N, odd ones included (the scalar-peel kernel ran
+                                   // those at 5.8-5.9 TB/s)
     bool have_problem = false, have_matrix = false, have_rhs = false, cg_ready = false;
     int k_done = 0;                // CG iterations enqueued since cg_init
     std::vector<ShardBase> sh;     // local shards
@@ -172,6 +178,14 @@ struct lam_hip_ctx {
     uint64_t ex1_stride_bytes() const { return ex1_base() * esz_v() + 8; }
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
+    static uint64_t pitch_for(uint64_t n, size_t ea)
+    {
+        const uint64_t align = n * ea >= 4096 ? 4096 / ea : 16 / ea;     // elements
+        return (n + align - 1) / align * align;
+    }
+    // columns the 16-byte-vector kernels cover: n rounded up to a whole vector (the extra columns are zeros of the padding,
+    // met by zeros behind the end of p)
+    uint64_t ncols_vec() const { const uint64_t v = 16 / esz_a(); return (n + v - 1) / v * v; }
     size_t esz_v() const { return dtype == LAM_HIP_F64 ? 8 : 4; }
 };
 

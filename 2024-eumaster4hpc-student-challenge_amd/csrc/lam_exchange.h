@@ -529,7 +529,7 @@ int enqueue_shard_direct(lam_hip_ctx *c, ShardBase &s, int k, double rel_error, 
         uint64_t a = s.row0, b = s.row0 + s.nrows;
         // option "overlap" = 0: no own-slice panel -- wait for the flags first, then one GEMV launch (the split
         // costs ~8 us of launch and ramp; it pays when the slices arrive later than that)
-        if (P > 1 && c->opt_overlap && (!I::fast_ok(c) || (a % I::VEC == 0 && b % I::VEC == 0))) { lo = a; hi = b; }
+        if (P > 1 && c->opt_overlap && (!I::fast_ok(c) || (a % I::VEC == 0 && (b % I::VEC == 0 || b == c->n)))) { lo = a; hi = b; }
         Finalize fa = no_finalize(c);
         fa.active = 1; fa.mail = 1; fa.seq = seq; fa.slot = 0; fa.dst.n = P;
         for (int q = 0; q < P; q++) fa.dst.p[q] = &c->peer_mail[q]->pap[me];

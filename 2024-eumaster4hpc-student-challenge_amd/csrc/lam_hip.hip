@@ -203,6 +203,7 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
     if (n == 0) return fail(c, LAM_HIP_EINVAL, "n must be > 0");
     if (n < (uint64_t)c->total_shards) return fail(c, LAM_HIP_EINVAL, "n (%llu) smaller than the number of shards", (unsigned long long)n);
     c->n = n;
+    c->lda = lam_hip_ctx::pitch_for(n, c->esz_a());
     c->problem_gen++;              // peers' mappings of the old p replica are stale from here on
     c->have_problem = c->have_matrix = c->have_rhs = c->cg_ready = false;
     const size_t ea = c->esz_a(), ev = c->esz_v();
@@ -214,14 +215,16 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         free_shard(s, c->opt_reuse_matrix != 0);
         partition(n, c->total_shards, s.index, &s.row0, &s.nrows);
         LAMCHK(set_dev(c, s));
-        const size_t needA = std::max<size_t>(16, s.nrows * n * ea);
+        const size_t needA = std::max<size_t>(16, s.nrows * c->lda * ea);
         if (s.A != nullptr && s.A_capacity < needA) { (void)hipFree(s.A); s.A = nullptr; s.A_capacity = 0; }
         if (s.A == nullptr) {
             HIPCHK(c, hipMalloc(&s.A, needA));
             s.A_capacity = needA;
         }
-        HIPCHK(c, hipMalloc(&s.p, n * ev + 16));
-        HIPCHK(c, hipMalloc(&s.tmp, n * ev + 16));
+        // p and tmp are what the GEMV reads as its vector: the vector kernels read whole 16-byte vectors of the matrix row, so up
+        // to 7 elements behind the end of the vector are touched (against zeros of the row padding): allocated and kept ZERO
+        HIPCHK(c, hipMalloc(&s.p, n * ev + 64));
+        HIPCHK(c, hipMalloc(&s.tmp, n * ev + 64));
         void **vecs[] = {&s.Ap, &s.x, &s.r, &s.b};
         for (auto v : vecs) HIPCHK(c, hipMalloc(v, s.nrows * ev + 16));
         s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
@@ -247,7 +250,11 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         HIPCHK(c, hipMemsetAsync(s.sc, 0, sizeof(CgScalars), s.stream));
         HIPCHK(c, hipMemsetAsync(s.gather_a, 0, sizeof(double) * kMaxShards, s.stream));
         HIPCHK(c, hipMemsetAsync(s.gather_b, 0, sizeof(double) * kMaxShards, s.stream));
-        HIPCHK(c, hipMemsetAsync(s.p, 0, n * ev, s.stream));
+        HIPCHK(c, hipMemsetAsync(s.p, 0, n * ev + 64, s.stream));
+        HIPCHK(c, hipMemsetAsync(s.tmp, 0, n * ev + 64, s.stream));
+        // the padding columns of the matrix must read as zero (they meet the zeros behind p, and 0 x garbage could be a NaN):
+        // one memset of the shard when rows are padded at all (a round N = 65536 has no padding and costs nothing here)
+        if (c->lda != n) HIPCHK(c, hipMemsetAsync(s.A, 0, s.nrows * c->lda * ea, s.stream));
         memset(s.sc_host, 0, sizeof(CgScalars));
     }
     LAMCHK(sync_all(c));
@@ -298,29 +305,33 @@ static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, 
         LAMCHK(set_dev(c, s));
         const uint64_t cnt = (hi - lo) * c->n;
         char *hptr = (char *)host + (lo - row0) * c->n * eh;
-        char *dptr = (char *)s.A + (lo - s.row0) * c->n * ea;
-        if (c->dtype == LAM_HIP_BF16) {
-            // stage through a device float buffer in chunks of rows
-            const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / (c->n * 4));
+        char *dptr = (char *)s.A + (lo - s.row0) * c->lda * ea;
+        if (c->dtype == LAM_HIP_BF16 || c->lda != c->n) {
+            // The device rows are padded (pitch lda > N) and / or of another type than the host's (bf16 storage travels as float):
+            // whole rows go through a DENSE device staging buffer with ONE contiguous copy per chunk (the rate of the plain path:
+            // the runtime pins the caller's pages), and a kernel moves them between the two layouts at HBM speed.
+            const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / (c->n * eh));
             DevBuf stage_buf;
-            HIPCHK(c, hipMalloc(&stage_buf.p, chunk_rows * c->n * 4));
-            float *stage = stage_buf.as<float>();
+            HIPCHK(c, hipMalloc(&stage_buf.p, std::min<uint64_t>(chunk_rows, hi - lo) * c->n * eh));
             for (uint64_t r = lo; r < hi; r += chunk_rows) {
-                const uint64_t nr = std::min(chunk_rows, hi - r), ne = nr * c->n;
-                char *hp = (char *)host + (r - row0) * c->n * 4;
-                __hip_bfloat16 *dp = (__hip_bfloat16 *)s.A + (r - s.row0) * c->n;
-                if (upload) {
-                    HIPCHK(c, hipMemcpyAsync(stage, hp, ne * 4, hipMemcpyHostToDevice, s.stream));
-                    hipLaunchKernelGGL((f32_to_bf16_kernel<float>), dim3(1024), dim3(kBlock), 0, s.stream, stage, dp, ne);
-                    HIPCHK(c, hipGetLastError());
-                    HIPCHK(c, hipStreamSynchronize(s.stream));
+                const uint64_t nr = std::min(chunk_rows, hi - r);
+                char *hp = (char *)host + (r - row0) * c->n * eh;
+                char *dp = (char *)s.A + (r - s.row0) * c->lda * ea;
+                if (upload) HIPCHK(c, hipMemcpyAsync(stage_buf.p, hp, nr * c->n * eh, hipMemcpyHostToDevice, s.stream));
+                const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(4096, (nr * c->n + kBlock - 1) / kBlock)));
+                if (c->dtype == LAM_HIP_BF16) {
+                    if (upload) hipLaunchKernelGGL((pitch_copy_kernel<float, __hip_bfloat16>), grid, dim3(kBlock), 0, s.stream, (const float *)stage_buf.p, c->n, (__hip_bfloat16 *)dp, c->lda, nr, c->n);
+                    else hipLaunchKernelGGL((pitch_copy_kernel<__hip_bfloat16, float>), grid, dim3(kBlock), 0, s.stream, (const __hip_bfloat16 *)dp, c->lda, (float *)stage_buf.p, c->n, nr, c->n);
+                } else if (c->dtype == LAM_HIP_F64) {
+                    if (upload) hipLaunchKernelGGL((pitch_copy_kernel<double, double>), grid, dim3(kBlock), 0, s.stream, (const double *)stage_buf.p, c->n, (double *)dp, c->lda, nr, c->n);
+                    else hipLaunchKernelGGL((pitch_copy_kernel<double, double>), grid, dim3(kBlock), 0, s.stream, (const double *)dp, c->lda, (double *)stage_buf.p, c->n, nr, c->n);
                 } else {
-                    std::vector<unsigned short> tmp(ne);
-                    HIPCHK(c, hipMemcpyAsync(tmp.data(), dp, ne * 2, hipMemcpyDeviceToHost, s.stream));
-                    HIPCHK(c, hipStreamSynchronize(s.stream));
-                    float *fp = (float *)hp;
-                    for (uint64_t i = 0; i < ne; i++) { unsigned u = ((unsigned)tmp[i]) << 16; memcpy(&fp[i], &u, 4); }
+                    if (upload) hipLaunchKernelGGL((pitch_copy_kernel<float, float>), grid, dim3(kBlock), 0, s.stream, (const float *)stage_buf.p, c->n, (float *)dp, c->lda, nr, c->n);
+                    else hipLaunchKernelGGL((pitch_copy_kernel<float, float>), grid, dim3(kBlock), 0, s.stream, (const float *)dp, c->lda, (float *)stage_buf.p, c->n, nr, c->n);
                 }
+                HIPCHK(c, hipGetLastError());
+                if (!upload) HIPCHK(c, hipMemcpyAsync(hp, stage_buf.p, nr * c->n * eh, hipMemcpyDeviceToHost, s.stream));
+                HIPCHK(c, hipStreamSynchronize(s.stream));
             }
         } else if (upload && c->opt_upload_staging) {
             // Option "upload_staging": pipeline through two pinned buffers -- a host memcpy into one
@@ -379,7 +390,7 @@ int lam_hip_generate_tridiag(lam_hip_ctx *c)
         for (auto &s : c->sh) {
             if (s.nrows == 0) continue;
             LAMCHK(set_dev(c, s));
-            hipLaunchKernelGGL((gen_tridiag_kernel<TA>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, c->n);
+            hipLaunchKernelGGL((gen_tridiag_kernel<TA>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, c->lda, s.row0, s.nrows, c->n);
             HIPCHK(c, hipGetLastError());
         }
         return 0;
@@ -399,7 +410,7 @@ int lam_hip_generate_random_spd(lam_hip_ctx *c, uint64_t seed, double cond)
         for (auto &s : c->sh) {
             if (s.nrows == 0) continue;
             LAMCHK(set_dev(c, s));
-            hipLaunchKernelGGL((gen_random_spd_kernel<TA>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, c->n, seed, cond);
+            hipLaunchKernelGGL((gen_random_spd_kernel<TA>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, c->lda, s.row0, s.nrows, c->n, seed, cond);
             HIPCHK(c, hipGetLastError());
         }
         return 0;
@@ -444,7 +455,7 @@ int lam_hip_generate_spectrum_spd(lam_hip_ctx *c, const double *eig, const doubl
         for (auto &s : c->sh) {
             if (s.nrows == 0) continue;
             LAMCHK(set_dev(c, s));
-            hipLaunchKernelGGL((gen_diag_kernel<TA, TV>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, n, (const TV *)s.tmp);
+            hipLaunchKernelGGL((gen_diag_kernel<TA, TV>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, c->lda, s.row0, s.nrows, n, (const TV *)s.tmp);
             HIPCHK(c, hipGetLastError());
         }
         return 0;
@@ -473,7 +484,7 @@ int lam_hip_generate_spectrum_spd(lam_hip_ctx *c, const double *eig, const doubl
             for (auto &s : c->sh) {
                 if (s.nrows == 0) continue;
                 LAMCHK(set_dev(c, s));
-                hipLaunchKernelGGL((rank2_update_kernel<TA, TV>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, s.row0, s.nrows, n,
+                hipLaunchKernelGGL((rank2_update_kernel<TA, TV>), dim3(4096), dim3(kBlock), 0, s.stream, (TA *)s.A, c->lda, s.row0, s.nrows, n,
                                    (const TV *)s.tmp, (const TV *)s.p);
                 HIPCHK(c, hipGetLastError());
             }
@@ -930,7 +941,7 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
         if constexpr (sizeof(TA) == 2) {
             return fail(c, LAM_HIP_EINVAL, "symmetry check is implemented for fp64/fp32 storage");
         } else {
-            hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->n, out);
+            hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->lda, c->n, out);
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(h.data(), out, sizeof(double) * grid, hipMemcpyDeviceToHost, s.stream);
             if (e == hipSuccess) e = hipStreamSynchronize(s.stream);

@@ -27,7 +27,7 @@ int decide_persistent(lam_hip_ctx *c)
         if constexpr (!std::is_same<TA, TV>::value) {
             return 0;
         } else {
-            if (!I::fast_ok(c) || s.nrows != c->n || (c->n % 2) != 0) return 0;
+            if (!I::fast_ok(c) || s.nrows != c->n || (c->n % 2) != 0 || (c->n % I::VEC) != 0) return 0;
             int per_cu = 0, cus = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_persist_kernel<TA, TV>, kBlock, 0) != hipSuccess ||
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.dev) != hipSuccess) {
@@ -67,7 +67,7 @@ int enqueue_persist_chunk(lam_hip_ctx *c, int k_first, int count, double rel_err
             ShardBase &s = c->sh[0];
             LAMCHK(set_dev(c, s));
             PersistArgs<TA, TV> a;
-            a.A = (const TA *)s.A; a.n = c->n;
+            a.A = (const TA *)s.A; a.n = c->n; a.lda = c->lda;
             a.pbuf[0] = (TV *)s.p; a.pbuf[1] = (TV *)s.tmp;
             a.r = (TV *)s.r; a.x = (TV *)s.x; a.Ap = (TV *)s.Ap;
             a.part_gemv = s.part_gemv; a.part_vec = s.part_vec;

@@ -435,6 +435,8 @@ struct GemvArgs {
     const CgScalars *sc;    // may be null; if sc->stop the kernel does nothing
     uint64_t nrows;         // local rows
     uint64_t n;             // columns (= global N)
+    uint64_t lda;           // row pitch of A in elements (>= n): rows are padded to a 4-KiB multiple (16 B for tiny rows) and the
+                            // padding is ZERO, so every row starts aligned and the 16-byte-vector kernels serve any N
     uint64_t row0;          // global index of local row 0 (for the fused dot)
     // column panels: the launch covers columns [seg_begin[i], seg_end[i]) for i < nseg (nseg <= 2).
     // A whole GEMV is one segment [0,n).  In rank mode the iteration's GEMV is two launches: the
@@ -484,7 +486,6 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint64_t n = a.n;
     const uint64_t row_first = ((uint64_t)blockIdx.x * kWaves + wave) * R;
 
     const TA *rowp[R];
@@ -492,7 +493,7 @@ gemv_tile_kernel(GemvArgs<TA, TV> a)
     for (int r = 0; r < R; r++) {
         uint64_t row = row_first + r;
         if (row >= a.nrows) row = a.nrows - 1;   // keep loads in bounds; result discarded below
-        rowp[r] = a.A + row * n + (uint64_t)lane * VEC;
+        rowp[r] = a.A + row * a.lda + (uint64_t)lane * VEC;
     }
     TV acc[R];
 #pragma unroll
@@ -625,7 +626,6 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint64_t n = a.n;
     const uint64_t row_first = (uint64_t)blockIdx.x * R;
     const uint32_t woff = (uint32_t)wave * STEP + (uint32_t)lane * VEC;   // this lane's column inside a super-step
 
@@ -634,7 +634,7 @@ gemv_coop_kernel(GemvArgs<TA, TV> a)
     for (int r = 0; r < R; r++) {
         uint64_t row = row_first + r;
         if (row >= a.nrows) row = a.nrows - 1;
-        rowp[r] = a.A + row * n + woff;
+        rowp[r] = a.A + row * a.lda + woff;
     }
     TV acc[R];
 #pragma unroll
@@ -846,7 +846,7 @@ gemv_coop_group_kernel(GemvArgs<TA, TV> a)
             for (int r = 0; r < R; r++) {
                 uint64_t row = row_first + (uint64_t)g * R + r;
                 if (row >= a.nrows) row = a.nrows - 1;
-                rowp[r] = a.A + row * n + woff;
+                rowp[r] = a.A + row * a.lda + woff;
             }
             coop_stream_tile<TA, TV, R, TILE, true, UNROLL, WAVES>(rowp, c0, cols, s_p, woff, acc[g]);
         }
@@ -916,7 +916,6 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint64_t n = a.n;
     const uint64_t row_first = ((uint64_t)blockIdx.x * kWaves + wave) * R;
 
     const __hip_bfloat16 *rowp[R];
@@ -924,7 +923,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
     for (int r = 0; r < R; r++) {
         uint64_t row = row_first + r;
         if (row >= a.nrows) row = a.nrows - 1;
-        rowp[r] = a.A + row * n + (uint64_t)lane * 8;
+        rowp[r] = a.A + row * a.lda + (uint64_t)lane * 8;
     }
     mfma_f32x16 acc[R];
 #pragma unroll
@@ -1167,7 +1166,7 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
 // max |A[i][j] - A[j][i]| over the local matrix (single shard), per-workgroup maxima in out[]
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-asymmetry_kernel(const T *__restrict__ A, uint64_t n, double *__restrict__ out)
+asymmetry_kernel(const T *__restrict__ A, uint64_t lda, uint64_t n, double *__restrict__ out)
 {
     __shared__ double s_max[kWaves];
     double m = 0.0;
@@ -1175,7 +1174,7 @@ asymmetry_kernel(const T *__restrict__ A, uint64_t n, double *__restrict__ out)
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint64_t i = idx / n, j = idx % n;
         if (j > i) {
-            const double d = fabs((double)A[idx] - (double)A[j * n + i]);
+            const double d = fabs((double)A[i * lda + j] - (double)A[j * lda + i]);
             m = d > m ? d : m;
         }
     }
@@ -1203,7 +1202,7 @@ gemv_generic_kernel(GemvArgs<TA, TV> a)
     const uint64_t row = (uint64_t)blockIdx.x * kWaves + wave;
     double dotp = 0.0;
     if (row < a.nrows) {
-        const TA *ar = a.A + row * a.n;
+        const TA *ar = a.A + row * a.lda;
         TV acc = (TV)0;
         using MV = MatVec<TA>;
         using avec_t = typename MV::vec_t;
@@ -1651,6 +1650,7 @@ template <typename TA, typename TV>
 struct PersistArgs {
     const TA *A;
     uint64_t n;
+    uint64_t lda;                 // row pitch of A in elements
     TV *pbuf[2];                  // [0] the shard's p (explicit on entry and on exit), [1] a scratch vector
     TV *r, *x, *Ap;
     double *part_gemv;            // [npairs], armed with the sentinel
@@ -1826,7 +1826,7 @@ cg_persist_kernel(PersistArgs<TA, TV> a)
                     if (q < a.npairs) {
                         const TA *rowp[R];
 #pragma unroll
-                        for (int r = 0; r < R; r++) rowp[r] = lane0 + (q * R + r) * n;
+                        for (int r = 0; r < R; r++) rowp[r] = lane0 + (q * R + r) * a.lda;
                         coop_stream_tile<TA, TV, R, TILE, true, UNROLL, WAVES>(rowp, c0, cols, s_p, woff, acc[g]);
                     }
                 }
@@ -1991,7 +1991,7 @@ template <> __device__ __forceinline__ __hip_bfloat16 to_storage<__hip_bfloat16>
 // rows [row0,row0+nrows) of dense tridiag(1,2,1) by GLOBAL row index
 template <typename TA>
 __global__ void __launch_bounds__(kBlock)
-gen_tridiag_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n)
+gen_tridiag_kernel(TA *__restrict__ A, uint64_t lda, uint64_t row0, uint64_t nrows, uint64_t n)
 {
     const uint64_t total = nrows * n;
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
@@ -1999,13 +1999,13 @@ gen_tridiag_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n
         double v = 0.0;
         if (i == j) v = 2.0;
         else if (i + 1 == j || i == j + 1) v = 1.0;
-        A[idx] = to_storage<TA>(v);
+        A[(i - row0) * lda + j] = to_storage<TA>(v);
     }
 }
 
 template <typename TA>
 __global__ void __launch_bounds__(kBlock)
-gen_random_spd_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, uint64_t seed, double cond)
+gen_random_spd_kernel(TA *__restrict__ A, uint64_t lda, uint64_t row0, uint64_t nrows, uint64_t n, uint64_t seed, double cond)
 {
     const uint64_t total = nrows * n;
     const double inv_n = 1.0 / (double)n;
@@ -2018,7 +2018,7 @@ gen_random_spd_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_
             const uint64_t lo = i < j ? i : j, hi = i < j ? j : i;
             v = (2.0 * u01(splitmix64(seed + splitmix64(lo * n + hi))) - 1.0) * inv_n;
         }
-        A[idx] = to_storage<TA>(v);
+        A[(i - row0) * lda + j] = to_storage<TA>(v);
     }
 }
 
@@ -2029,12 +2029,12 @@ gen_random_spd_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_
 // A <- A - (tau v) u^T - u (tau v)^T  by the kernel below.
 template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)
-gen_diag_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ eig /* full length */)
+gen_diag_kernel(TA *__restrict__ A, uint64_t lda, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ eig /* full length */)
 {
     const uint64_t total = nrows * n;
     for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
         const uint64_t i = idx / n + row0, j = idx % n;
-        A[idx] = i == j ? to_storage<TA>((double)eig[i]) : to_storage<TA>(0.0);
+        A[(i - row0) * lda + j] = i == j ? to_storage<TA>((double)eig[i]) : to_storage<TA>(0.0);
     }
 }
 
@@ -2042,7 +2042,7 @@ gen_diag_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, c
 // (j, i) adds the same two products in the other order, and a + b == b + a, so a symmetric A stays symmetric bit for bit.
 template <typename TA, typename TV>
 __global__ void __launch_bounds__(kBlock)
-rank2_update_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ tv, const TV *__restrict__ u)
+rank2_update_kernel(TA *__restrict__ A, uint64_t lda, uint64_t row0, uint64_t nrows, uint64_t n, const TV *__restrict__ tv, const TV *__restrict__ u)
 {
 #pragma clang fp contract(off)      // plain operators under contract(off): nothing here may be fused into an fma -- fma(tv_i, u_j,
                                     // u_i tv_j) rounds one product and not the other, and (i, j) != (j, i) in the last bit.  (The
@@ -2054,7 +2054,8 @@ rank2_update_kernel(TA *__restrict__ A, uint64_t row0, uint64_t nrows, uint64_t 
         const TV p1 = tv[i] * u[j];
         const TV p2 = u[i] * tv[j];
         const TV s12 = p1 + p2;
-        A[idx] = to_storage<TA>((double)((TV)A[idx] - s12));
+        TA *e = A + (i - row0) * lda + j;
+        *e = to_storage<TA>((double)((TV)*e - s12));
     }
 }
 
@@ -2066,12 +2067,19 @@ gen_rhs_kernel(TV *__restrict__ b, uint64_t row0, uint64_t n_loc, int random, ui
         b[i] = random ? (TV)(2.0 * u01(splitmix64(seed ^ splitmix64(0xB5ull + row0 + i))) - 1.0) : (TV)value;
 }
 
-template <typename TV>
+// rows of `cols` elements between a dense staging buffer (pitch = cols) and the matrix (pitch = lda), either direction;
+// TD <- TS conversion by to_storage (float -> bf16 rounds, bf16 -> float widens, same type copies)
+template <typename TS, typename TD>
 __global__ void __launch_bounds__(kBlock)
-f32_to_bf16_kernel(const float *__restrict__ src, __hip_bfloat16 *__restrict__ dst, uint64_t n)
+pitch_copy_kernel(const TS *__restrict__ src, uint64_t src_pitch, TD *__restrict__ dst, uint64_t dst_pitch, uint64_t nrows, uint64_t cols)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
-        dst[i] = __float2bfloat16(src[i]);
+    const uint64_t total = nrows * cols;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t r = idx / cols, j = idx % cols;
+        if constexpr (std::is_same<TS, TD>::value) dst[r * dst_pitch + j] = src[r * src_pitch + j];
+        else if constexpr (std::is_same<TD, __hip_bfloat16>::value) dst[r * dst_pitch + j] = __float2bfloat16((float)src[r * src_pitch + j]);
+        else dst[r * dst_pitch + j] = (TD)__bfloat162float(src[r * src_pitch + j]);
+    }
 }
 
 }  // namespace lam

@@ -34,7 +34,9 @@ struct Impl {
         return rows[v];
     }
 
-    static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic && (c->n % VEC) == 0; }
+    // rows are padded to a multiple of 16 bytes at least (lam_hip_ctx::lda), so the vector kernels serve any N; the any-alignment
+    // kernel runs on request only (option force_generic: tests, comparisons)
+    static bool fast_ok(const lam_hip_ctx *c) { return !c->opt_generic; }
     static int variant(const lam_hip_ctx *c)
     {
         if (c->opt_gemv_variant >= 0 && variant_available((int)c->opt_gemv_variant)) return (int)c->opt_gemv_variant;
@@ -156,14 +158,18 @@ struct Impl {
             for (int j = 0; j < ypeers->n && a.n_ypeer < kMaxShards - 1; j++) a.ypeer[a.n_ypeer++] = (TV *)ypeers->p[j];
         if (fin != nullptr && partial != nullptr) a.fin = *fin;
         else { a.fin.active = 0; a.fin.mail = 0; a.fin.seq = 0; a.fin.dst.n = 0; a.fin.slot = 0; a.fin.host_err = c->direct_err; }
-        a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0;
-        a.seg_begin[0] = 0; a.seg_end[0] = c->n; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
+        a.nrows = s.nrows; a.n = c->n; a.row0 = s.row0; a.lda = c->lda;
+        // the vector kernels cover whole 16-byte vectors: for an N that is not a multiple of the vector width the last one
+        // reaches into the (zero) padding of the row and behind the end of p (zero too: set_problem)
+        const uint64_t ncols = fast_ok(c) ? c->ncols_vec() : c->n;
+        if (fast_ok(c) && hi == c->n) hi = ncols;
+        a.seg_begin[0] = 0; a.seg_end[0] = ncols; a.seg_begin[1] = a.seg_end[1] = 0; a.nseg = 1; a.accumulate = 0;
         if (panel == 1) { a.seg_begin[0] = lo; a.seg_end[0] = hi; }
         else if (panel == 2) {
             a.accumulate = 1;
             a.nseg = 0;
             if (lo > 0) { a.seg_begin[a.nseg] = 0; a.seg_end[a.nseg] = lo; a.nseg++; }
-            if (hi < c->n) { a.seg_begin[a.nseg] = hi; a.seg_end[a.nseg] = c->n; a.nseg++; }
+            if (hi < ncols) { a.seg_begin[a.nseg] = hi; a.seg_end[a.nseg] = ncols; a.nseg++; }
             if (a.nseg == 0) return 0;
             if (a.nseg == 1) { a.seg_begin[1] = a.seg_end[1] = 0; }
         }
@@ -224,7 +230,7 @@ void cg_panel(const lam_hip_ctx *c, const ShardBase &s, uint64_t *lo, uint64_t *
     if (c->opt_panel_hi > c->opt_panel_lo) { a = (uint64_t)c->opt_panel_lo; b = std::min<uint64_t>((uint64_t)c->opt_panel_hi, c->n); }
     else if (c->rank_mode && c->opt_overlap && c->nranks > 1) { a = s.row0; b = s.row0 + s.nrows; }
     if (b <= a || (a == 0 && b >= c->n)) return;
-    if (I::fast_ok(c) && (a % I::VEC != 0 || b % I::VEC != 0)) return;
+    if (I::fast_ok(c) && (a % I::VEC != 0 || (b % I::VEC != 0 && b != c->n))) return;
     *lo = a; *hi = b;
 }
 
