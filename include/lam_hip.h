@@ -103,7 +103,8 @@ const char *lam_hip_last_error(const lam_hip_ctx *ctx); /* ctx may be NULL: last
 /* ---- problem definition ------------------------------------------------------------------- */
 
 /* Fix N, compute the reference row partition and allocate A (rows_loc x N, row-major, per
- * shard) and the work vectors.  Stands in for the allocation half of load_matrix_from_file /
+ * shard; on the device every row is padded to a whole number of 4-KiB pages -- an internal layout, upload / download take and
+ * give dense rows -- so that any N, odd ones included, streams through the aligned 16-byte-vector kernels) and the work vectors.  Stands in for the allocation half of load_matrix_from_file /
  * generate_matrix (ConjugateGradient_CPU_MPI_OMP.hpp:176-196,214,250-253;
  * ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:544-568). */
 int lam_hip_set_problem(lam_hip_ctx *ctx, uint64_t n);
@@ -305,7 +306,8 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   configs[3]'s comparison, measured slower than the VALU kernel (bench.py measures it in a child process
  *                   on the tuning build).
  *   "nt_loads"      1 (default) = non-temporal loads for the matrix stream.
- *   "force_generic" 1 = always use the any-N scalar-load GEMV.
+ *   "force_generic" 1 = use the any-alignment scalar-peel GEMV (tests and comparisons; since the rows are padded on the device
+ *                   the vector kernels serve every N and this kernel is never chosen by itself).
  *   "probe_rows"    lam_hip_gemv_only: use only the first ROWS rows of a shard (a P-way split's shape).
  *   "panel_lo/hi"   testing: split the CG GEMV into the column panel [lo,hi) + the rest (accumulated). */
 int lam_hip_set_option(lam_hip_ctx *ctx, const char *name, int64_t value);
