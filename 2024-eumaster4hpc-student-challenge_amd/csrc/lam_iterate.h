@@ -27,7 +27,9 @@ int decide_persistent(lam_hip_ctx *c)
         if constexpr (!std::is_same<TA, TV>::value) {
             return 0;
         } else {
-            if (!I::fast_ok(c) || s.nrows != c->n || (c->n % 2) != 0 || (c->n % I::VEC) != 0) return 0;
+            // the launch's GEMV phase is the tile body of the 2-rows-per-4-wave-workgroup shape (variant 10): it is bit-identical to
+            // the two-launch chain only when that chain runs the same shape
+            if (!I::fast_ok(c) || I::variant(c) != 10 || s.nrows != c->n || (c->n % 2) != 0 || (c->n % I::VEC) != 0) return 0;
             int per_cu = 0, cus = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cg_persist_kernel<TA, TV>, kBlock, 0) != hipSuccess ||
                 hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.dev) != hipSuccess) {

@@ -11,9 +11,12 @@ struct Impl {
 
     // GEMV shapes.  Variants 0-8: gemv_tile_kernel {rows per wave, p-tile columns, p in LDS, rotated
     // tile order}; 9-18: gemv_coop_kernel {rows per workgroup, tile, waves}; 19-22: the MFMA experiment (bf16).
-    // The PRODUCT library holds the shapes that are some dtype's default: 10 (cooperative rows, 2 rows per 4-wave
-    // workgroup: fp64/fp32 production, fastest at N=65536 and N=32768, profiles/r01_gemv_variant_sweep.txt) and 0 (4 rows
-    // per wave: bf16 production).  Everything else -- the other tile / cooperative shapes, the grouped probe and the
+    // The PRODUCT library holds the shapes that are some dtype's default: 13 (cooperative rows, 2 rows per EIGHT-wave
+    // workgroup: fp64 production since round 4 -- half as many concurrent row streams as the 4-wave shape, each read 8 KiB at a
+    // time: equal at N=65536, 0.4-2.3 % faster at every other size from 8192 to 131072, profiles/r04_variant_vs_size.txt),
+    // 10 (the same with 4 waves: fp32 production, where the two are level), 0 (4 rows per wave: bf16 production) and 17 (4 rows
+    // per 8-wave workgroup: an OPTION, 0.5-0.8 % faster than 13 at exactly 16 column tiles -- N=65536, and its row shards -- and
+    // slower almost everywhere else; not selected by size).  Everything else -- the other tile / cooperative shapes, the grouped probe and the
     // MFMA-fed bf16 GEMV of BASELINE configs[3]'s comparison (slower than the VALU kernel) -- exists only in the library
     // built with -DLAM_TUNING_VARIANTS (`make tuning` -> liblam_hip_tuning.so; tools/gemv_probe.py, bench.py's MFMA child).
     static constexpr int kNumVariants = 25;      // 23, 24: tuning probes gemv_coop_group_kernel (2 / 4 row pairs per workgroup)
@@ -22,7 +25,7 @@ struct Impl {
 #ifdef LAM_TUNING_VARIANTS
         return v >= 0 && v < kNumVariants;
 #else
-        return v == 0 || v == 10;
+        return v == 0 || v == 10 || v == 13 || v == 17;
 #endif
     }
     // rows per WORKGROUP of each variant (variants 9.. are the cooperative-row shape: R rows per workgroup)
@@ -40,9 +43,9 @@ struct Impl {
     static int variant(const lam_hip_ctx *c)
     {
         if (c->opt_gemv_variant >= 0 && variant_available((int)c->opt_gemv_variant)) return (int)c->opt_gemv_variant;
-        // production shapes: fp64/fp32 -> cooperative rows (variant 10); bf16 storage spends more VALU
-        // per byte (widening) and measures best with 4 rows per wave (variant 0, 6.77 vs 6.40 TB/s)
-        return sizeof(TA) == 2 ? 0 : 10;
+        // production shapes: fp64 -> cooperative rows, 8 waves (variant 13); fp32 -> cooperative rows, 4 waves (variant 10);
+        // bf16 storage spends more VALU per byte (widening) and measures best with 4 rows per wave (variant 0)
+        return sizeof(TA) == 2 ? 0 : (sizeof(TA) == 8 ? 13 : 10);
     }
 
     // name of the kernel instantiation launch_gemv() picks for this context (roofline records)
@@ -179,6 +182,8 @@ struct Impl {
             default:
             case 0: launch_tile<4, 4096, true, true>(c, grid, s.stream, a); break;
             case 10: launch_coop<2>(c, grid, s.stream, a); break;
+            case 13: launch_coop<2, 4096, 8>(c, grid, s.stream, a); break;
+            case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
 #ifdef LAM_TUNING_VARIANTS
             case 1: launch_tile<2, 4096, true, true>(c, grid, s.stream, a); break;
             case 2: launch_tile<8, 4096, true, true>(c, grid, s.stream, a); break;
@@ -191,11 +196,9 @@ struct Impl {
             case 9: launch_coop<1>(c, grid, s.stream, a); break;
             case 11: launch_coop<4>(c, grid, s.stream, a); break;
             case 12: launch_coop<8>(c, grid, s.stream, a); break;
-            case 13: launch_coop<2, 4096, 8>(c, grid, s.stream, a); break;
             case 14: launch_coop<2, 2048, 4, 4>(c, grid, s.stream, a); break;
             case 15: launch_coop<2, 8192, 8, 8>(c, grid, s.stream, a); break;
             case 16: launch_coop<2, 8192, 4, 8>(c, grid, s.stream, a); break;
-            case 17: launch_coop<4, 4096, 8>(c, grid, s.stream, a); break;
             case 18: launch_coop<3>(c, grid, s.stream, a); break;
             case 23: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 2>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
             case 24: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;

@@ -89,6 +89,7 @@ def persistent(dtype_name, n):
         with lam.Solver(dt) as s:
             s.generate_random_spd(n, 5, 300.0)
             s.generate_random_rhs(6)
+            s.set_option("gemv_variant", 10)        # the shape whose tile body the persistent launch shares (fp64 default is 13)
             s.set_option("persistent", pers)
             s.set_option("persist_chunk", chunk)
             s.solve(400, tol)

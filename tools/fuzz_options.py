@@ -54,6 +54,11 @@ def main():
         if TUNING:
             opts.update({"finalize": rng.choice((1, 1, 0)), "host_threads": rng.choice((0, 1)), "exchange_hub": rng.choice((0, 1)),
                          "persistent": rng.choice((0, 1)), "persist_chunk": rng.choice((1, 2, 7, 32))})
+            if opts["persistent"]:
+                # the persistent launch shares the tile body of GEMV shape 10 (fp64's default is 13): same shape on both sides
+                base = dict(base, gemv_variant=10)
+                opts["gemv_variant"] = 10
+                ref = run(dt, n, shards, seed, base, [total])
         if direct and shards > 1 and exchange == 0:
             # the in-kernel flag exchange between the local shards, one GEMV launch per shard (the own-slice panel of
             # overlap = 1 adds a row's products in another order): same bits as the event exchange; needs finalize = 1
