@@ -630,7 +630,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         // hipStreamSynchronize would spin a core for up to kLag iterations), then synchronise for real
         Progress pr;
         LAMCHK(set_dev(c, s0));
-        LAMCHK(await_progress(c, s0, k_first + enq - 1, &pr));
+        LAMCHK(await_progress(c, s0, k_first + enq - 1, &pr, /*precise=*/true));
     }
     LAMCHK(settle_gather(c));
     LAMCHK(sync_all(c));

@@ -284,12 +284,18 @@ Progress read_progress(const ShardBase &s)
 // proxy threads): after a short spin -- an iteration that is about to report costs nothing -- it SLEEPS between polls,
 // for a quarter of the iteration time observed so far (clamped to 20 us .. 1 ms).  The host enqueues kLag iterations
 // ahead of the one it awaits, so a wake-up that comes a whole iteration late is still free: the queue never drains.
-int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
+// `precise` = the wait that ENDS a call (for the last enqueued iteration): there a late wake-up is latency of the call -- a
+// 1 ms nap too many is 1 % of a 20-iteration run at N=65536 -- so the naps shrink with the time the awaited iteration is
+// expected to need (half of it at a time, from the observed iteration time and the moment the progress word last moved) and
+// the last ~300 us are polled.
+int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out, bool precise = false)
 {
     unsigned polls = 0;
-    double t_query = 0.0;
+    double t_query = 0.0, t_change = 0.0;
+    int last_iters = -1;
     for (;;) {
         const Progress pr = read_progress(s0);
+        if (precise && pr.iters != last_iters) { last_iters = pr.iters; t_change = now_s(); }
         if (pr.iters >= target || pr.stop_at != 0 || *(volatile int *)c->direct_err != 0) {
             // iteration-time estimate: progress made since the previous successful wait / time since then
             const double t = now_s();
@@ -326,7 +332,16 @@ int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out)
             if ((polls & 63u) == 0) sched_yield(); else __builtin_ia32_pause();
             continue;
         }
-        const double nap = std::min(1e-3, std::max(15e-6, 0.25 * c->iter_est_s));
+        double nap = std::min(1e-3, std::max(15e-6, 0.25 * c->iter_est_s));
+        if (precise) {
+            const double est = c->iter_est_s;
+            const double left = est > 0.0 ? (double)(target - pr.iters - 1) * est + std::max(0.0, est - (t - t_change)) : 0.0;
+            if (left < 300e-6) {                         // nearly there (or nothing known yet): poll
+                if ((polls & 63u) == 0) sched_yield(); else __builtin_ia32_pause();
+                continue;
+            }
+            nap = std::min(1e-3, 0.5 * left);
+        }
         struct timespec ts = {0, (long)(nap * 1e9)};
         (void)nanosleep(&ts, nullptr);
     }
