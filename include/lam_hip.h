@@ -299,9 +299,13 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.  Exchange 2: 1 runs
  *                   that own-columns panel in front of the wait for the peers' p slices; 0 waits first and
  *                   launches the GEMV once.
- *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype (10 for fp64/fp32, 0 for bf16).  Every other shape
+ *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype: 13 for fp64 (cooperative rows, 2 rows per 8-wave
+ *                   workgroup), 10 for fp32 (the same with 4 waves), 0 for bf16 (4 rows per wave).  17 (4 rows per 8-wave
+ *                   workgroup) is an alternative in the product library: 0.5-0.8 % faster than 13 for matrices of exactly 16
+ *                   column tiles (N = 65536 and its row shards), slower nearly everywhere else
+ *                   (profiles/r04_variant_vs_size.txt) -- never selected by size.  Every other shape
  *                   is TUNING BUILD ONLY ("tuning_variants" tells which build this is) and refused with LAM_HIP_EINVAL by the
- *                   product library: 1-9, 11-18, 23, 24 tile / cooperative-row shapes (tools/gemv_probe.py), 19-22 the MFMA-fed
+ *                   product library: 1-9, 11, 12, 14-16, 18, 23, 24 tile / cooperative-row shapes (tools/gemv_probe.py), 19-22 the MFMA-fed
  *                   bf16 GEMV (20: p rounded to bf16, 21: p exact as three bf16 terms; LAM_HIP_BF16 only) -- BASELINE
  *                   configs[3]'s comparison, measured slower than the VALU kernel (bench.py measures it in a child process
  *                   on the tuning build).
