@@ -19,7 +19,8 @@ struct Impl {
     // slower almost everywhere else; not selected by size).  Everything else -- the other tile / cooperative shapes, the grouped probe and the
     // MFMA-fed bf16 GEMV of BASELINE configs[3]'s comparison (slower than the VALU kernel) -- exists only in the library
     // built with -DLAM_TUNING_VARIANTS (`make tuning` -> liblam_hip_tuning.so; tools/gemv_probe.py, bench.py's MFMA child).
-    static constexpr int kNumVariants = 25;      // 23, 24: tuning probes gemv_coop_group_kernel (2 / 4 row pairs per workgroup)
+    static constexpr int kNumVariants = 28;      // 23, 24: tuning probes gemv_coop_group_kernel (2 / 4 row pairs per workgroup);
+                                                 // 25-27: cooperative rows with 8192-column tiles and 4 / 8 rows (bf16 probes, round 4)
     static bool variant_available(int v)
     {
 #ifdef LAM_TUNING_VARIANTS
@@ -33,7 +34,8 @@ struct Impl {
     {
         static const int rows[kNumVariants] = {16, 8, 32, 16, 16, 8, 16, 16, 4, 1, 2, 4, 8, 2, 2, 2, 2, 4, 3,
                                                   /* 19-22: MFMA bf16 experiment (bf16 storage only) */ 8, 8, 16, 4,
-                                                  /* 23, 24: grouped cooperative rows (tuning probe) */ 4, 8};
+                                                  /* 23, 24: grouped cooperative rows (tuning probe) */ 4, 8,
+                                                  /* 25-27: coop R4 T8192 W4, R4 T8192 W8, R8 T8192 W8 */ 4, 4, 8};
         return rows[v];
     }
 
@@ -71,6 +73,8 @@ struct Impl {
         else if (v <= 18)
             snprintf(buf, sizeof buf, "gemv_coop_kernel<%s,%s,R=%d,TILE=%d,NT=%s,UNROLL=%d,WAVES=%d>", ta, tv, coops[v - 9].r,
                      coops[v - 9].tile, nt, coops[v - 9].unroll, coops[v - 9].waves);
+        else if (v >= 25)
+            snprintf(buf, sizeof buf, "gemv_coop_kernel<%s,%s,R=%d,TILE=8192,NT=%s,UNROLL=4,WAVES=%d>", ta, tv, v == 27 ? 8 : 4, nt, v == 25 ? 4 : 8);
         else if (v >= 23)
             snprintf(buf, sizeof buf, "gemv_coop_group_kernel<%s,%s,GROUP=%d>", ta, tv, v == 23 ? 2 : 4);
         else {
@@ -202,6 +206,9 @@ struct Impl {
             case 18: launch_coop<3>(c, grid, s.stream, a); break;
             case 23: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 2>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
             case 24: hipLaunchKernelGGL((gemv_coop_group_kernel<TA, TV, 4>), dim3(grid), dim3(kBlock), 0, s.stream, a); break;
+            case 25: launch_coop<4, 8192, 4, 4>(c, grid, s.stream, a); break;
+            case 26: launch_coop<4, 8192, 8, 4>(c, grid, s.stream, a); break;
+            case 27: launch_coop<8, 8192, 8, 4>(c, grid, s.stream, a); break;
             case 19: case 20: case 21: case 22:
                 if constexpr (sizeof(TA) == 2) {
                     const int v = variant(c);

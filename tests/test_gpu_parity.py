@@ -872,8 +872,8 @@ def test_tuning_build_variants(lam):
         for opt, val in (("persistent", 0), ("host_threads", 0), ("exchange_hub", 0), ("finalize", 1)):
             s.set_option(opt, val)                     # switching them OFF is always accepted
     probe = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "gemv_probe.py")
-    for dtype, variants in (("f64", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,23,24"), ("f32", "0,8,9,10,12,15,18,23"),
-                            ("bf16", "0,1,10,19,20,21,22")):
+    for dtype, variants in (("f64", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,23,24,25"), ("f32", "0,8,9,10,12,15,18,23,26"),
+                            ("bf16", "0,1,10,19,20,21,22,25,26,27")):
         r = subprocess.run([sys.executable, probe, "4104", "8192", "--check", "--dtype", dtype, "--variants", variants],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "FAIL" not in r.stdout and r.stdout.count(" ok") == 2 * len(variants.split(",")), r.stdout + r.stderr[-2000:]

@@ -10,7 +10,7 @@ lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 NAMES = {0: "R4 T4096 lds rot (default)", 1: "R2 T4096", 2: "R8 T4096", 3: "R4 T2048", 4: "R4 T8192", 5: "R2 T8192",
          6: "R4 T4096 p-from-L2", 7: "R4 T4096 no-rot", 8: "R1 T4096", 9: "coop R1", 10: "coop R2", 11: "coop R4",
          12: "coop R8", 13: "coop R2 W8", 14: "coop R2 T2048", 15: "coop R2 W8 T8192 u8", 16: "coop R2 W4 T8192 u8",
-         17: "coop R4 W8", 18: "coop R3", 19: "MFMA bf16 R2 split3", 20: "MFMA bf16 R2 split1 (p->bf16)",
+         17: "coop R4 W8", 18: "coop R3", 25: "coop R4 T8192 W4", 26: "coop R4 T8192 W8", 27: "coop R8 T8192 W8", 19: "MFMA bf16 R2 split3", 20: "MFMA bf16 R2 split1 (p->bf16)",
          21: "MFMA bf16 R4 split3", 22: "MFMA bf16 R1 split3", 23: "coop R2 x2 pairs/WG", 24: "coop R2 x4 pairs/WG"}
 
 def check(a):
