@@ -203,6 +203,7 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
     if (n == 0) return fail(c, LAM_HIP_EINVAL, "n must be > 0");
     if (n < (uint64_t)c->total_shards) return fail(c, LAM_HIP_EINVAL, "n (%llu) smaller than the number of shards", (unsigned long long)n);
     c->n = n;
+    c->iter_est_s = 0.0;           // the observed iteration time belongs to the previous problem
     c->lda = lam_hip_ctx::pitch_for(n, c->esz_a());
     c->problem_gen++;              // peers' mappings of the old p replica are stale from here on
     c->have_problem = c->have_matrix = c->have_rhs = c->cg_ready = false;

@@ -301,7 +301,10 @@ int await_progress(lam_hip_ctx *c, ShardBase &s0, int target, Progress *out, boo
             const double t = now_s();
             if (c->prog_t > 0.0 && pr.iters > c->prog_iter && pr.stop_at == 0) {
                 const double per = (t - c->prog_t) / (double)(pr.iters - c->prog_iter);
-                c->iter_est_s = c->iter_est_s > 0.0 ? 0.75 * c->iter_est_s + 0.25 * per : per;
+                // smoothed, but a jump by more than 2x (another problem size, another exchange) is taken at once: a stale
+                // estimate would oversleep and drain the queue
+                const double e = c->iter_est_s;
+                c->iter_est_s = (e > 0.0 && per < 2.0 * e && per > 0.5 * e) ? 0.75 * e + 0.25 * per : per;
             }
             c->prog_t = t;
             c->prog_iter = pr.iters;
