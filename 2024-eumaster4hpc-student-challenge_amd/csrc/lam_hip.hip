@@ -1137,6 +1137,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "assume_cus")) *value = c->opt_assume_cus;
     else if (!strcmp(name, "host_enqueue_ns")) *value = (int64_t)c->enqueue_ns;
     else if (!strcmp(name, "host_cpu_ns")) *value = (int64_t)c->host_cpu_ns;
+    else if (!strcmp(name, "row_pitch")) *value = (int64_t)c->lda;
     else if (!strcmp(name, "hip_calls_launch")) *value = (int64_t)c->n_launch.load();
     else if (!strcmp(name, "hip_calls_record")) *value = (int64_t)c->n_record.load();
     else if (!strcmp(name, "hip_calls_wait")) *value = (int64_t)c->n_wait.load();

@@ -286,6 +286,8 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   Measured host cost of both: profiles/r03_host_enqueue_cost.txt.  Same bits in every combination.
  *   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "host_enqueue_ns" (get only): runtime calls issued and host
  *                   time spent by the iteration loop so far (diagnostics, tools/host_enqueue_cost.py).
+ *   "row_pitch"     (get only) elements between the starts of two consecutive matrix rows on the device: N rounded up to whole
+ *                   4-KiB pages (to 16 bytes for rows shorter than a page); the padding is zero.
  *   "host_cpu_ns"   (get only) CPU time (CLOCK_THREAD_CPUTIME_ID) the calling thread has spent inside lam_hip_cg_iterate:
  *                   the host SLEEPS between its polls of the iteration's progress word (a quarter of the observed iteration
  *                   time, 20 us .. 1 ms; it runs 4 iterations ahead of the one it awaits, so the queue never drains), it

@@ -509,6 +509,34 @@ def test_tiny_systems(lam, oracle):
             np.testing.assert_allclose(s.solution(), x_ref, rtol=1e-13)
 
 
+@pytest.mark.parametrize("dtype_name,n,pitch", [("F64", 65536, 65536), ("F64", 10000, 10240), ("F64", 10001, 10240), ("F64", 100, 100),
+                                                 ("F64", 101, 102), ("F32", 10000, 10240), ("F32", 1001, 1004), ("F32", 1025, 2048), ("BF16", 1003, 1008),
+                                                 ("BF16", 5000, 6144)])
+def test_rows_are_padded_to_pages_and_any_n_runs_the_vector_kernels(lam, dtype_name, n, pitch):
+    """Device rows start page-aligned (N rounded up to 4 KiB; to 16 B for rows shorter than a page) and the padding is zero, so the
+    16-byte-vector GEMV kernels serve every N -- odd ones too -- and upload / download keep giving dense rows."""
+    dt = getattr(lam, dtype_name)
+    with lam.Solver(dt) as s:
+        s.set_problem(n)
+        assert s.get_option("row_pitch") == pitch
+        assert "generic" not in s.gemv_kernel_name()
+        if n <= 1100:
+            A = _rand_matrix(n, n, n).astype(np.float32 if dtype_name != "F64" else np.float64)
+            s.upload_rows(0, A)
+            B = s.download_rows(0, n)
+            if dtype_name != "BF16":
+                assert np.array_equal(A, B)                                   # dense in, dense out, nothing of the padding
+            x = np.random.default_rng(n).uniform(-1, 1, n)
+            y = s.gemv(x).astype(np.float64)
+            y_ref = B.astype(np.float64) @ x.astype(s.vec_dtype).astype(np.float64)
+            scale = np.abs(B.astype(np.float64)) @ np.abs(x)
+            assert np.max(np.abs(y - y_ref) / scale) <= (1e-13 if dtype_name == "F64" else 32 * 2.0 ** -24)
+            s.set_option("force_generic", 1)
+            assert "generic" in s.gemv_kernel_name()
+            y_gen = s.gemv(x).astype(np.float64)
+            assert np.max(np.abs(y_gen - y_ref) / scale) <= (1e-13 if dtype_name == "F64" else 32 * 2.0 ** -24)
+
+
 def test_invalid_sizes_are_rejected(lam):
     with lam.Solver(lam.F64, n_shards=4, device_ids=[0] * 4) as s:
         with pytest.raises(lam.LamHipError) as e:
