@@ -311,7 +311,7 @@ static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, 
             // The device rows are padded (pitch lda > N) and / or of another type than the host's (bf16 storage travels as float):
             // whole rows go through a DENSE device staging buffer with ONE contiguous copy per chunk (the rate of the plain path:
             // the runtime pins the caller's pages), and a kernel moves them between the two layouts at HBM speed.
-            const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / (c->n * eh));
+            const uint64_t chunk_rows = std::max<uint64_t>(1, ((upload ? 256ull : 1024ull) << 20) / (c->n * eh));   // D2H to pageable memory likes big pieces
             DevBuf stage_buf;
             HIPCHK(c, hipMalloc(&stage_buf.p, std::min<uint64_t>(chunk_rows, hi - lo) * c->n * eh));
             for (uint64_t r = lo; r < hi; r += chunk_rows) {
