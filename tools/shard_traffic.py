@@ -58,10 +58,10 @@ def collect(n, shards, counter, work):
                   key=lambda x: int(x["Dispatch_Id"]))
     res, i, name = {}, 0, None
     for P in shards:
-        grid = (n // P) // 2 * 256                       # production shape: 2 rows per 256-thread workgroup
+        grids = {(n // P) // 2 * 256, (n // P) // 2 * 512}   # production shapes: 2 rows per 4-wave (round 1-3) / 8-wave (round 4) workgroup
         uns = rows[i:i + 1 + REPS]; i += 1 + REPS
         spl = rows[i:i + 2 * (1 + REPS)]; i += 2 * (1 + REPS)
-        assert all(int(x["Grid_Size"]) == grid for x in uns + spl), (P, grid, [x["Grid_Size"] for x in uns + spl])
+        assert all(int(x["Grid_Size"]) in grids for x in uns + spl), (P, grids, [x["Grid_Size"] for x in uns + spl])
         name = uns[0]["Kernel_Name"]
         res[P] = {"unsplit": sum(float(x["Counter_Value"]) for x in uns[1:]) / REPS,
                   "split": sum(float(x["Counter_Value"]) for x in spl[2:]) / REPS}
@@ -73,7 +73,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--shards", default="2,4,8")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r03_shard_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_shard_traffic.json"))
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     shards = [int(x) for x in a.shards.split(",")]
