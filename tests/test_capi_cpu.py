@@ -30,6 +30,25 @@ def test_binding_covers_header(lam):
     assert L.lam_hip_abi_version() == 2
 
 
+def test_build_id_covers_every_source_of_the_translation_unit(lam):
+    """The library is ONE translation unit, csrc/lam_hip.hip, that includes csrc/lam_*.h: the build id the binding checks (and the
+    Makefile's SRC_ID / stamp file) must hash every one of them, or an edited header would pass for the built library."""
+    import glob
+    from importlib import import_module
+    capi = import_module("2024-eumaster4hpc-student-challenge_amd._capi")
+    files = [os.path.relpath(f, ROOT) for f in capi._source_files()]
+    pkg = "2024-eumaster4hpc-student-challenge_amd"
+    assert files[0] == f"{pkg}/csrc/lam_hip.hip" and files[-1] == "include/lam_hip.h"
+    headers = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, pkg, "csrc", "*.h")))
+    assert files[1:-1] == headers and {"lam_kernels.h", "lam_ctx.h", "lam_launch.h", "lam_exchange.h", "lam_iterate.h"} <= {os.path.basename(h) for h in headers}
+    # every header is really included by the translation unit, and the Makefile hashes the same list
+    tu = open(os.path.join(ROOT, pkg, "csrc", "lam_hip.hip")).read()
+    assert all(f'#include "{os.path.basename(h)}"' in tu for h in headers)
+    mk = open(os.path.join(ROOT, pkg, "Makefile")).read()
+    assert "$(sort $(wildcard $(HERE)csrc/*.h))" in mk and "$(STAMP)" in mk
+    assert lam.lib().lam_hip_build_id().decode() == capi.source_id()
+
+
 def test_no_cpu_fallback(lam):
     """Without a GPU, creating a context must fail loudly with ENODEV."""
     import subprocess, sys
