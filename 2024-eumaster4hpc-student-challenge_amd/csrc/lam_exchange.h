@@ -498,17 +498,35 @@ bool timed_iteration(const lam_hip_ctx *c, const ShardBase &s, int k)
 // workgroups are admitted per CU up to min(occupancy API, 8) (MI355X_MICROARCH.md, residency); a CU mask or a
 // partitioned device that the runtime reports shows up in the CU count.  What the query cannot see (other kernels on
 // the device) is still caught by the bounded waits, which end in an error, never in a hang or a silent NaN.
-template <typename TV>
-bool fused_launch_resident(lam_hip_ctx *c, const ShardBase &s, int blocks)
+template <typename K>
+bool launch_resident(lam_hip_ctx *c, const ShardBase &s, K kernel, int blocks)
 {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, update_fused_kernel<TV>, kBlock, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s.dev) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     if (c->opt_assume_cus > 0) cus = (int)c->opt_assume_cus;
     return (int64_t)std::min(per_cu, 8) * (int64_t)cus >= (int64_t)blocks;
+}
+template <typename TV>
+bool fused_launch_resident(lam_hip_ctx *c, const ShardBase &s, int blocks)
+{
+    return launch_resident(c, s, update_fused_kernel<TV>, blocks);
+}
+// The gather-Ap exchange's fused vector step (update_full_fused_kernel): every shard launches vec_grid(n) + 1 workgroups that
+// wait for each other inside the launch.  Shards that share a device (an emulation; the product gives every shard a device of its
+// own) run those launches side by side on their streams, so ALL of them must fit on that device together.
+template <typename TV>
+bool full_fused_launch_resident(lam_hip_ctx *c)
+{
+    for (const auto &s : c->sh) {
+        int sharing = 0;
+        for (const auto &t : c->sh) sharing += t.dev == s.dev ? 1 : 0;
+        if (!launch_resident(c, s, update_full_fused_kernel<TV>, sharing * (vec_grid(c->n) + 1))) return false;
+    }
+    return true;
 }
 
 // One shard's iteration on the direct exchange: rank mode has one local shard (index = rank); one process with several
@@ -711,6 +729,8 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
             RECORD(c, c->ev_join[0], s0.stream);
         }
         const int grid = vec_grid(c->n);
+        const unsigned long long seq = c->seq_base + (unsigned)k;
+        c->seq_span = std::max<uint64_t>(c->seq_span, (uint64_t)k + 1);
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             if (c->opt_join) {
@@ -718,6 +738,14 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
             } else {
                 for (auto &t : c->sh)
                     if (&t != &s) WAITEV(c, s.stream, t.ev_a);
+            }
+            if (c->fuse_active) {
+                // the two vector kernels in ONE launch (r.r resolved by its reducer workgroup): 2 launches per shard and iteration
+                hipLaunchKernelGGL((update_full_fused_kernel<TV>), dim3(grid + 1), dim3(kBlock), 0, s.stream, (const char *)buf(s), stride,
+                                   base, P, s.sc, k, rel_error, (TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec,
+                                   grid, s.bcast, seq, c->direct_err, (volatile int *)s.host_flags);
+                LAUNCHED(c);
+                continue;
             }
             hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)buf(s), stride,
                                base, P, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
@@ -786,6 +814,16 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         c->n_collectives++;
         // 3. alpha, x slice, FULL r (+ partials of r.r over the full vector: no collective needed)
         const int grid = vec_grid(c->n);
+        if (c->fuse_active) {
+            // 3 + 4 in ONE launch: GEMV, collective, vector step
+            const unsigned long long seq = c->seq_base + (unsigned)k;
+            c->seq_span = std::max<uint64_t>(c->seq_span, (uint64_t)k + 1);
+            hipLaunchKernelGGL((update_full_fused_kernel<TV>), dim3(grid + 1), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
+                               base, c->nranks, s.sc, k, rel_error, (TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec,
+                               grid, s.bcast, seq, c->direct_err, (volatile int *)s.host_flags);
+            LAUNCHED(c);
+            return 0;
+        }
         hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
                            base, c->nranks, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
         LAUNCHED(c);

@@ -106,12 +106,15 @@ int do_cg_init(lam_hip_ctx *c)
     }
     // The fused vector step (one shard; the direct exchange) is a launch whose workgroups wait for each other: used
     // only when the whole grid (compute workgroups + reducer + waiter) can be resident at once, else the two-kernel form.
+    // The gather-Ap exchange has a fused vector step of its own (update_full_fused_kernel, full-length r and p).
     c->fuse_active = false;
-    if (c->opt_fuse && c->opt_finalize && (c->cg_direct || (!c->rank_mode && c->total_shards == 1))) {
+    const bool ex1 = !c->cg_direct && c->exchange1_ok();
+    if (c->opt_fuse && c->opt_finalize && (c->cg_direct || ex1 || (!c->rank_mode && c->total_shards == 1))) {
         ShardBase &s0 = c->sh[0];
         LAMCHK(set_dev(c, s0));
         c->fuse_active = dispatch(c, [&](auto impl) -> int {
             using TV = typename ImplTraits<decltype(impl)>::TV;
+            if (ex1) return full_fused_launch_resident<TV>(c) ? 1 : 0;
             return fused_launch_resident<TV>(c, s0, s0.vec_blocks + 2) ? 1 : 0;
         }) == 1;
     }

@@ -1613,6 +1613,64 @@ update_p_full_kernel(const double *__restrict__ red, int nred, CgScalars *sc, in
         p_full[i] = r_full[i] + beta * p_full[i];
 }
 
+// update_xr_full_kernel + update_p_full_kernel in ONE launch (round 4): what separates them is the grid-wide r.r, which the
+// reducer workgroup resolves inside the launch exactly as in update_fused_kernel -- compute workgroups publish their partials in
+// self-flagging slots, workgroup 0 sums them in the order of block_sum_array and hands {value, tag} to every compute workgroup on
+// a line of its own.  Same element -> thread mapping, same partial grouping and reduction order as the two kernels: bit-identical
+// (the number of compute workgroups equals the two-kernel grid).  The gather-Ap iteration is then GEMV + one collective or join +
+// this launch: two launches for every shard count, like the single-shard iteration.  All workgroups must be resident at once.
+template <typename TV>
+__global__ void __launch_bounds__(kBlock)
+update_full_fused_kernel(const char *__restrict__ gathered, uint64_t stride_bytes, uint64_t base, int nranks, CgScalars *sc, int k,
+                         double rel_error, TV *p_full, TV *__restrict__ x, TV *r_full, uint64_t n, uint64_t row0, uint64_t n_loc,
+                         double *partial, int ncompute, BcastLine *bc, unsigned long long seq, int *host_err, volatile int *host_flags)
+{
+    __shared__ double s_red[kWaves];
+    if (sc->stop) return;
+    if (blockIdx.x == 0) {                              // reducer: r.r of the full vector, to every compute workgroup
+        const double total = reduce_partials_sum(partial, ncompute, s_red, host_err);
+        bcast_post(bc, ncompute, total, seq);
+        return;
+    }
+    const int cb = (int)blockIdx.x - 1;
+    double pAp = 0.0;                                   // rank order, same on every shard
+    for (int q = 0; q < nranks; q++)
+        pAp += *reinterpret_cast<const double *>(gathered + (uint64_t)q * stride_bytes + base * sizeof(TV));
+    const double rr = sc->rr[(k + 1) & 1];
+    const double bb = sc->bb;
+    const double alpha_d = rr / pAp;
+    const TV alpha = (TV)alpha_d;
+    double acc = 0.0;
+    const uint64_t stride = (uint64_t)ncompute * kBlock;
+    for (uint64_t i = (uint64_t)cb * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t q = i / base;
+        const TV api = reinterpret_cast<const TV *>(gathered + q * stride_bytes)[i - q * base];
+        const TV ri = -alpha * api + r_full[i];
+        r_full[i] = ri;
+        acc += (double)ri * (double)ri;
+        if (i >= row0 && i < row0 + n_loc) x[i - row0] = alpha * p_full[i] + x[i - row0];
+    }
+    const double t = block_sum(acc, s_red);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + cb, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cb == 0) { sc->pAp = pAp; sc->alpha = alpha_d; }
+    }
+    const double rr_new = bcast_wait(bc + cb, seq, host_err, s_red);
+    const double beta_d = rr_new / rr;
+    const bool stop = sqrt(rr_new / bb) < rel_error;
+    if (cb == 0 && threadIdx.x == 0) {
+        sc->rr[k & 1] = rr_new;
+        sc->beta = beta_d;
+        sc->iters = k;
+        post_progress(host_flags, k, stop);
+        if (stop) sc->stop = 1;
+    }
+    if (stop) return;
+    const TV beta = (TV)beta_d;
+    for (uint64_t i = (uint64_t)cb * kBlock + threadIdx.x; i < n; i += stride)
+        p_full[i] = r_full[i] + beta * p_full[i];
+}
+
 #ifdef LAM_TUNING_VARIANTS
 // ---------------------------------------------------------------------------------------------
 // TUNING BUILD ONLY.

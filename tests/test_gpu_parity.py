@@ -707,7 +707,7 @@ def test_launch_chain_variants_are_bit_identical(lam, dtype_name, n, shards):
     """The iteration's vector work exists in two launch shapes in the product -- fused update (one launch, the r.r total handed
     over inside the launch through the context's mailbox) and separate update_xr / update_p with the reducer workgroup --
     which must be the same arithmetic: identical iteration counts, residuals and solution bits.  (Several shards in one
-    process always use the two-kernel form; fuse_update is then ignored.)  The round-1 chain with separate reduction launches
+    process run the gather-Ap exchange, whose full-length vector step has a fused form of its own: update_full_fused_kernel.)  The round-1 chain with separate reduction launches
     (finalize = 0) is a tuning-build option and is compared there, on both event-ordered exchanges (tuning_cases.py)."""
     dt = getattr(lam, dtype_name)
     res = []
@@ -770,26 +770,36 @@ def test_one_process_gather_ap_exchange(lam, shards, n, dtype_name):
     dt = getattr(lam, dtype_name)
     tol = 1e-9 if dtype_name == "F64" else 1e-5
     res = {}
-    for label, exchange, join in (("events", 0, 1), ("gather_ap", 1, 1), ("gather_ap_all_to_all", 1, 0)):
+    for label, exchange, join, fuse in (("events", 0, 1, 1), ("gather_ap", 1, 1, 1), ("gather_ap_all_to_all", 1, 0, 1),
+                                        ("gather_ap_two_kernels", 1, 1, 0)):
         with lam.Solver(dt, device_ids=[0] * shards) as s:
             s.generate_random_spd(n, 7, 200.0)
             s.generate_random_rhs(8)
             s.set_option("exchange", exchange)
             s.set_option("exchange_join", join)
+            s.set_option("fuse_update", fuse)
             s.solve(500, tol)
             assert s.stats["converged"]
             eff = s.get_option("exchange_effective")
-            out = dict(iters=s.stats["num_iters"], err=s.stats["rel_err"], x=s.solution(), res=s.true_residual(), eff=eff)
+            out = dict(iters=s.stats["num_iters"], err=s.stats["rel_err"], x=s.solution(), res=s.true_residual(), eff=eff,
+                       fused=s.get_option("fuse_effective"))
             s.cg_init()
+            l0 = s.get_option("hip_calls_launch")
             for chunk in (1, 2, 9, 30):
                 s.cg_iterate(chunk, 0.0)
+            out["launches"] = (s.get_option("hip_calls_launch") - l0) / 42
             out["x42"], out["err42"] = s.solution(), s.stats["rel_err"]
             res[label] = out
-    a, b, e = res["gather_ap"], res["gather_ap_all_to_all"], res["events"]
-    assert a["eff"] == b["eff"] == (1 if n % shards == 0 else 0) and e["eff"] == 0
+    a, b, e, t = res["gather_ap"], res["gather_ap_all_to_all"], res["events"], res["gather_ap_two_kernels"]
+    assert a["eff"] == b["eff"] == t["eff"] == (1 if n % shards == 0 else 0) and e["eff"] == 0
     for k in ("iters", "err", "err42"):
-        assert a[k] == b[k], k
+        assert a[k] == b[k] == t[k], k
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["x42"], b["x42"])
+    assert np.array_equal(a["x"], t["x"]) and np.array_equal(a["x42"], t["x42"])
+    if a["eff"] == 1:
+        # the full-length vector step in ONE launch (update_full_fused_kernel) or as two kernels: GEMV + 1 or GEMV + 2 per shard
+        assert (a["fused"], t["fused"]) == (1, 0)
+        assert abs(a["launches"] - 2 * shards) < 0.01 and abs(t["launches"] - 3 * shards) < 0.01, (a["launches"], t["launches"])
     if a["eff"] == 0:                                   # fell back: the very same path as the default
         assert np.array_equal(a["x"], e["x"]) and a["iters"] == e["iters"]
     assert abs(a["iters"] - e["iters"]) <= 2

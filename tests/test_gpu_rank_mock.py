@@ -124,6 +124,11 @@ def test_one_process_gather_ap_is_bit_identical_to_rank_mode_gather_ap(mock_asyn
     r, out, lines = _run(mock_async, tmp_path, P, n, "spd", "--exchange", 1, "--no-single")
     _check_mock_stats(lines, P)
     assert out["exchange_effective"] == [1] * P
+    # the rank mode's vector step as two kernels (fuse_update 0) instead of update_full_fused_kernel: same bits
+    os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
+    r2, out2, lines2 = _run(mock_async, tmp_path, P, n, "spd", "--exchange", 1, "--fuse", 0, "--no-single")
+    _check_mock_stats(lines2, P)
+    assert (out2["iters"], out2["rel_err"], out2["x_sha"]) == (out["iters"], out["rel_err"], out["x_sha"]), (out, out2)
     lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
     for join in (1, 0):
         with lam.Solver(lam.F64, device_ids=[0] * P) as s:
