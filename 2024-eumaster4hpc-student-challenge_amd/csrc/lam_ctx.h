@@ -39,6 +39,7 @@ struct ShardBase {
     size_t ap_gather_bytes = 0;
     void *symv_rowpart = nullptr, *symv_colpart = nullptr;   // symmetric product (option "symmetric")
     SymvTask *symv_tasks = nullptr;
+    uint32_t *symv_slot_base = nullptr;   // [strips + 1]: first colpart slot of every strip
     int symv_ntasks = 0;
     double *part_gemv = nullptr; // [gemv_blocks]
     double *part_vec = nullptr;  // [vec_blocks]
@@ -160,12 +161,8 @@ struct lam_hip_ctx {
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
-    // the symmetric product exists for one shard, fp64/fp32 storage, n a multiple of its column tile
-    uint64_t symv_tile() const { return 8ull * kBlock * (16 / esz_a()); }
-    bool symv_active() const
-    {
-        return opt_symmetric && !rank_mode && total_shards == 1 && dtype != LAM_HIP_BF16 && n > 0 && n % symv_tile() == 0;
-    }
+    // the symmetric product exists for one shard and fp64/fp32 storage (any n)
+    bool symv_active() const { return opt_symmetric && !rank_mode && total_shards == 1 && dtype != LAM_HIP_BF16 && n > 0; }
 
     bool exchange2_wanted() const { return (rank_mode || total_shards > 1) && opt_exchange == 2 && opt_finalize != 0; }
     // gather-Ap needs equal slices and an 8-byte aligned tail for the double (total_shards == nranks in rank mode)

@@ -1031,128 +1031,241 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
 // ---------------------------------------------------------------------------------------------
 // Symmetric product (option "symmetric", single shard): y = A p reading only the UPPER triangle.
 // CG needs A symmetric positive definite, so A[i][j] (j > i) can serve both y_i += A_ij p_j and
-// y_j += A_ij p_i: 18.4 GB per product instead of 34.4 GB at N=65536 fp64 -- the only way past the
-// HBM roofline of the plain GEMV.  Two passes:
-//   symv_task_kernel    one workgroup per task = 32 rows x 8 super-steps of columns (a super-step is
-//                       the 4 KiB the 4 waves read contiguously per row), for the column tiles at or
-//                       right of the diagonal.  A lane keeps 32 row partials (its columns x 32 rows) in
-//                       registers across the tile and one column partial per owned column across the
-//                       32 rows, flushed once per super-step to colpart[I][c]; elements on or left of
-//                       the diagonal inside the diagonal block are masked (diagonal counted once).
-//   symv_reduce_kernel  y[i] = sum_j rowpart[I][j][i%32] + sum_{I'<=I} colpart[I'][i], fixed order
-//                       (deterministic), plus the workgroup's partial of p.y for the CG.
-// The caller asserts symmetry (lam_hip_check_symmetry measures it).  n must be a multiple of the tile.
+// y_j += A_ij p_i: 17.2 GB per product instead of 34.4 GB at N=65536 fp64 -- the only way past the
+// HBM roofline of the plain GEMV.  Two passes (round 4: second shape; the round-1 shape flushed a column
+// partial per 32 rows -- 0.55 GB written and read again per product -- and kept 32 row partials per lane):
+//   symv_task_kernel    one workgroup per TASK = a column strip (NV x 4 KiB per row, read contiguously by the
+//                       4 waves: 512 / 1024 fp64 columns, twice that in fp32) x a run of rows (256 for most
+//                       of the triangle, 32 for the rows dispatched last, so that the launch ends on short
+//                       tasks; shorter runs for small N).  A lane keeps the column partials of its columns in
+//                       registers over ALL rows of the task and 8 row partials at a time: every 8 rows they
+//                       are summed across the wave by a transposed butterfly (wave_sum8: 7 exchanged values
+//                       for 8 rows instead of 48) and parked in LDS until the task ends.  Tasks are dispatched
+//                       row block by row block, all strips of a row block side by side: whole rows stream, as
+//                       in the GEMV.  Elements left of the diagonal are masked (not even read where a whole
+//                       16-byte vector lies left of it); the diagonal counts once.
+//   symv_reduce_kernel  y[i] = sum_{strips s at or right of i} rowpart[s][i] + sum_{tasks t of i's strip}
+//                       colpart[t][i - c0], fixed order (deterministic), plus the workgroup's partial of p.y.
+// Partials: ~0.17 GB written and read per product at N=65536.  Any N (rows are padded to whole vectors with zeros,
+// p likewise).  The caller asserts symmetry (lam_hip_check_symmetry measures it).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSymvRows = 32;
-template <typename T> struct SymvShape {
-    static constexpr int VEC = 16 / sizeof(T);
-    static constexpr int SS = kBlock * VEC;          // columns per super-step
-    static constexpr int TILE = 8 * SS;              // columns per task
-};
-struct SymvTask { uint32_t I, j; };
+constexpr int kSymvRowsMax = 256;      // rows of the tallest task (LDS row-partial buffer)
+constexpr int kSymvReduceRows = 32;    // rows per workgroup of the second pass = p.Ap partials per product: ceil(n / 32)
+struct SymvTask { uint32_t row0, nrows, strip, slot; };   // slot: this task's row of colpart (slots of a strip are consecutive)
 
-template <typename T>
-__global__ void __launch_bounds__(kBlock)
-symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks,
-                 T *__restrict__ rowpart, T *__restrict__ colpart, uint64_t n, uint32_t ntiles, const CgScalars *sc)
+// lane exchanges of the transposed butterfly.  gfx950: v_permlane32_swap / v_permlane16_swap move both directions of a
+// halving step in one instruction (no select, no LDS crossbar); inside a 16-lane row DPP: rotation by 8 (= lane ^ 8),
+// half-row mirror (lane -> 7 - lane within 8 lanes), quad permutes (lane ^ 2, lane ^ 1).
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u32(unsigned v) { return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float dpp_t(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
+template <int CTRL> __device__ __forceinline__ double dpp_t(double v)
 {
-    using SH = SymvShape<T>;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = dpp_u32<CTRL>((unsigned)u), hi = dpp_u32<CTRL>((unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int W> __device__ __forceinline__ void permlane_swap(unsigned &x, unsigned &y)
+{
+    if (W == 32) { auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); x = r[0]; y = r[1]; }
+    else { auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false); x = r[0]; y = r[1]; }
+}
+// x belongs to the lower half (of 2W lanes), y to the upper: lower lanes return x(l) + x(l + W), upper lanes y(l - W) + y(l)
+template <int W> __device__ __forceinline__ float fold_halves(float x, float y)
+{
+    unsigned a = __float_as_uint(x), b = __float_as_uint(y);
+    permlane_swap<W>(a, b);
+    return __uint_as_float(a) + __uint_as_float(b);
+}
+template <int W> __device__ __forceinline__ double fold_halves(double x, double y)
+{
+    const unsigned long long ux = (unsigned long long)__double_as_longlong(x), uy = (unsigned long long)__double_as_longlong(y);
+    unsigned xl = (unsigned)ux, xh = (unsigned)(ux >> 32), yl = (unsigned)uy, yh = (unsigned)(uy >> 32);
+    permlane_swap<W>(xl, yl);
+    permlane_swap<W>(xh, yh);
+    return __longlong_as_double((long long)(((unsigned long long)xh << 32) | xl)) +
+           __longlong_as_double((long long)(((unsigned long long)yh << 32) | yl));
+}
+// 8 per-lane values -> lane L returns the wave total of value (L >> 3) & 7.  Fixed order.
+template <typename T>
+__device__ __forceinline__ T wave_sum8(const T (&v)[8])
+{
+    const bool b3 = threadIdx.x & 8;
+    T w[4], u[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = fold_halves<32>(v[j], v[4 + j]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) u[j] = fold_halves<16>(w[j], w[2 + j]);
+    const T keep = b3 ? u[1] : u[0], send = b3 ? u[0] : u[1];
+    T t = keep + dpp_t<0x128>(send);      // row_ror:8
+    t += dpp_t<0x141>(t);                 // row_half_mirror
+    t += dpp_t<0x4e>(t);                  // quad_perm [2,3,0,1]
+    t += dpp_t<0xb1>(t);                  // quad_perm [1,0,3,2]
+    return t;
+}
+
+template <typename T, int NV>
+__global__ void __launch_bounds__(kBlock)
+symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks, T *__restrict__ rowpart,
+                 T *__restrict__ colpart, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch, const CgScalars *sc)
+{
     using MV = MatVec<T>;
     using vec_t = typename MV::vec_t;
-    constexpr int VEC = SH::VEC, RB = kSymvRows;
-    __shared__ T s_pr[RB];
-    __shared__ T s_red[RB][kWaves];
+    constexpr int VEC = MV::N, CW = kBlock * VEC, SS = NV * CW;     // CW: columns the workgroup covers with one vector per lane
+    __shared__ T s_rows[kWaves][kSymvRowsMax];
     if (sc != nullptr && sc->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SymvTask t = tasks[blockIdx.x];
-    const uint64_t r0 = (uint64_t)t.I * RB;
-    if (tid < RB) s_pr[tid] = p[r0 + tid];
-    __syncthreads();
-    const uint32_t cw = ((uint32_t)wave * 64 + (uint32_t)lane) * VEC;
-    T racc[RB];
+    const uint64_t c0 = (uint64_t)t.strip * SS, c = c0 + (uint64_t)tid * VEC;       // this lane's columns: c + v * CW + i
+    const bool masked = (uint64_t)t.row0 + t.nrows > c0;                             // the task's rows meet the strip's columns
+    bool live[NV];                                                                   // columns behind the row's end: nothing to do
+    vec_t pc[NV];
+    T cacc[NV][VEC];
 #pragma unroll
-    for (int r = 0; r < RB; r++) racc[r] = (T)0;
-
-    const uint64_t tile0 = (uint64_t)t.j * SH::TILE;
-    const T *Arow = A + r0 * n;
-    for (int ss = 0; ss < SH::TILE / SH::SS; ss++) {
-        const uint64_t c_ss = tile0 + (uint64_t)ss * SH::SS;
-        if (c_ss + SH::SS <= r0) continue;                     // entirely in the lower triangle
-        const uint64_t c = c_ss + cw;                          // this lane's VEC columns
-        const vec_t pc = *reinterpret_cast<const vec_t *>(p + c);
-        T cacc[VEC];
+    for (int v = 0; v < NV; v++) {
+        live[v] = c + (uint64_t)v * CW < ncols_vec;
 #pragma unroll
-        for (int i = 0; i < VEC; i++) cacc[i] = (T)0;
-        const bool masked = c_ss < r0 + RB;                    // the super-step touches the diagonal block
-#pragma unroll
-        for (int sub = 0; sub < RB / 8; sub++) {
-            vec_t a[8];
+        for (int i = 0; i < VEC; i++) { pc[v][i] = (T)0; cacc[v][i] = (T)0; }
+        if (live[v]) pc[v] = *reinterpret_cast<const vec_t *>(p + c + (uint64_t)v * CW);
+    }
+    // Interior tasks -- whole strip inside the rows, no diagonal, a whole number of 8-row steps: nearly all of the triangle -- take
+    // the lean loop: 8 * NV unconditional loads per lane from UNIFORM row bases plus the lane's constant offset (no per-load
+    // address arithmetic, no exec-mask juggling between the loads: the predicated form below issued its loads one branch at a
+    // time and spent half of its wave cycles on issue stalls), the 8 values of p for the rows by scalar loads.
+    const bool interior = !masked && c0 + SS <= ncols_vec && (t.nrows & 7u) == 0;
+    if (interior) {
+        const T *rows = A + (uint64_t)t.row0 * lda + c0;           // uniform
+        const T *prow = p + t.row0;
+        for (uint32_t b = 0; b < t.nrows; b += 8, rows += 8 * lda, prow += 8) {
+            vec_t a[8][NV];
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                a[k] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Arow + (uint64_t)(sub * 8 + k) * n + c));
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+                    a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)k * lda + v * CW) + tid);
+            T racc[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int r = sub * 8 + k;
-                const T pr = s_pr[r];
-                if (!masked) {
+                const T pr = prow[k];
+                T r = (T)0;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        racc[r] = fma_tv((T)a[k][i], (T)pc[i], racc[r]);
-                        cacc[i] = fma_tv((T)a[k][i], pr, cacc[i]);
+                        r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
+                        cacc[v][i] = fma_tv((T)a[k][v][i], pr, cacc[v][i]);
                     }
-                } else {
-                    const uint64_t row = r0 + r;               // (row, col): col > row both, col == row once
+                racc[k] = r;
+            }
+            const T tot = wave_sum8(racc);
+            if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
+        }
+    } else {
+    const T *Arow = A + (uint64_t)t.row0 * lda + c;
+    for (uint32_t b = 0; b < t.nrows; b += 8) {
+        vec_t a[8][NV];
+        T pr[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint64_t row = (uint64_t)t.row0 + b + k;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) a[k][v][i] = (T)0;
+                // masked tasks: a vector whose columns all lie left of the diagonal is not read at all
+                if (live[v] && b + k < t.nrows && (!masked || c + (uint64_t)v * CW + VEC > row))
+                    a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Arow + (uint64_t)(b + k) * lda + (uint64_t)v * CW));
+            }
+            pr[k] = b + k < t.nrows ? p[row] : (T)0;
+        }
+        T racc[8];
+        if (!masked) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                T r = (T)0;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        if (c + i >= row) racc[r] = fma_tv((T)a[k][i], (T)pc[i], racc[r]);
-                        if (c + i > row) cacc[i] = fma_tv((T)a[k][i], pr, cacc[i]);
+                        r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
+                        cacc[v][i] = fma_tv((T)a[k][v][i], pr[k], cacc[v][i]);
                     }
-                }
+                racc[k] = r;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint64_t row = (uint64_t)t.row0 + b + k;
+                T r = (T)0;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) {             // (row, col): col > row serves both, col == row once
+                        const uint64_t col = c + (uint64_t)v * CW + i;
+                        if (col >= row) r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
+                        if (col > row) cacc[v][i] = fma_tv((T)a[k][v][i], pr[k], cacc[v][i]);
+                    }
+                racc[k] = r;
             }
         }
-        vec_t out;
-#pragma unroll
-        for (int i = 0; i < VEC; i++) out[i] = cacc[i];
-        *reinterpret_cast<vec_t *>(colpart + (uint64_t)t.I * n + c) = out;
+        const T tot = wave_sum8(racc);
+        if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
+    }
     }
 #pragma unroll
-    for (int r = 0; r < RB; r++) {
-        const T sum = wave_sum(racc[r]);
-        if (lane == 0) s_red[r][wave] = sum;
-    }
+    for (int v = 0; v < NV; v++)
+        if (live[v]) {
+            vec_t out;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) out[i] = cacc[v][i];
+            *reinterpret_cast<vec_t *>(colpart + (uint64_t)t.slot * SS + (uint64_t)v * CW + (uint64_t)tid * VEC) = out;
+        }
     __syncthreads();
-    if (tid < RB) {
-        T v = s_red[tid][0];
-#pragma unroll
-        for (int w = 1; w < kWaves; w++) v += s_red[tid][w];
-        rowpart[((uint64_t)t.I * ntiles + t.j) * RB + tid] = v;
-    }
+    for (uint32_t r = tid; r < t.nrows; r += kBlock)
+        rowpart[(uint64_t)t.strip * row_pitch + t.row0 + r] = (s_rows[0][r] + s_rows[1][r]) + (s_rows[2][r] + s_rows[3][r]);
 }
 
-// one workgroup per row block: thread (cx, iy) sums colpart[I'][i] for I' = iy, iy+8, ... <= I
-template <typename T>
+// 32 rows per workgroup; the terms of a row are dealt round-robin to 8 groups of 32 lanes (four loads in flight per lane)
+// and combined in a fixed order
+template <typename T, int NV>
 __global__ void __launch_bounds__(kBlock)
-symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const T *__restrict__ p, T *__restrict__ y,
-                   double *__restrict__ partial, uint64_t n, uint32_t ntiles, const CgScalars *sc)
+symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const uint32_t *__restrict__ slot_base,
+                   const T *__restrict__ p, T *__restrict__ y, double *__restrict__ partial, uint64_t n, uint64_t row_pitch,
+                   uint32_t nstrips, const CgScalars *sc)
 {
-    constexpr int RB = kSymvRows;
-    __shared__ T s[kBlock / RB][RB];
+    constexpr int SS = NV * kBlock * MatVec<T>::N, RB = kSymvReduceRows, G = kBlock / RB;
+    __shared__ T s[G][RB];
     __shared__ double s_dot[RB];
     if (sc != nullptr && sc->stop) return;
-    const int cx = threadIdx.x % RB, iy = threadIdx.x / RB;
-    const uint64_t I = blockIdx.x, i = I * RB + cx;
+    const int l = threadIdx.x % RB, g = threadIdx.x / RB;
+    const uint64_t i = (uint64_t)blockIdx.x * RB + l;
     T acc = (T)0;
-    for (uint64_t Ip = iy; Ip <= I; Ip += kBlock / RB) acc += colpart[Ip * n + i];
-    s[iy][cx] = acc;
+    if (i < n) {
+        const uint32_t s0 = (uint32_t)(i / SS);
+        uint32_t q = s0 + g;
+        for (; q + 3 * G < nstrips; q += 4 * G) {
+            const T a0 = rowpart[(uint64_t)q * row_pitch + i], a1 = rowpart[(uint64_t)(q + G) * row_pitch + i];
+            const T a2 = rowpart[(uint64_t)(q + 2 * G) * row_pitch + i], a3 = rowpart[(uint64_t)(q + 3 * G) * row_pitch + i];
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        for (; q < nstrips; q += G) acc += rowpart[(uint64_t)q * row_pitch + i];
+        const uint32_t e = slot_base[s0 + 1];
+        const uint64_t col = i - (uint64_t)s0 * SS;
+        uint32_t k = slot_base[s0] + g;
+        for (; k + 3 * G < e; k += 4 * G) {
+            const T a0 = colpart[(uint64_t)k * SS + col], a1 = colpart[(uint64_t)(k + G) * SS + col];
+            const T a2 = colpart[(uint64_t)(k + 2 * G) * SS + col], a3 = colpart[(uint64_t)(k + 3 * G) * SS + col];
+            acc += (a0 + a1) + (a2 + a3);
+        }
+        for (; k < e; k += G) acc += colpart[(uint64_t)k * SS + col];
+    }
+    s[g][l] = acc;
     __syncthreads();
-    if (iy == 0) {
-        T t = (T)0;
+    if (g == 0) {
+        T t = s[0][l];
 #pragma unroll
-        for (int k = 0; k < kBlock / RB; k++) t += s[k][cx];
-        const uint32_t jd = (uint32_t)((I * RB) / SymvShape<T>::TILE);
-        for (uint32_t j = jd; j < ntiles; j++) t += rowpart[(I * ntiles + j) * RB + cx];
-        y[i] = t;
-        s_dot[cx] = (double)t * (double)p[i];
+        for (int k = 1; k < G; k++) t += s[k][l];
+        if (i < n) y[i] = t;
+        s_dot[l] = i < n ? (double)t * (double)p[i] : 0.0;
     }
     __syncthreads();
     if (threadIdx.x == 0 && partial != nullptr) {

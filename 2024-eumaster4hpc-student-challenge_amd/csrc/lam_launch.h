@@ -56,7 +56,7 @@ struct Impl {
         const char *ta = sizeof(TA) == 8 ? "double" : (sizeof(TA) == 4 ? "float" : "__hip_bfloat16");
         const char *tv = sizeof(TV) == 8 ? "double" : "float";
         char buf[192];
-        if (c->symv_active()) { snprintf(buf, sizeof buf, "symv_task_kernel<%s> + symv_reduce_kernel<%s>", ta, ta); return buf; }
+        if (c->symv_active()) { snprintf(buf, sizeof buf, "symv_task_kernel<%s,NV=%d> + symv_reduce_kernel<%s,NV=%d>", ta, symv_nv(c), ta, symv_nv(c)); return buf; }
         if (!fast_ok(c)) { snprintf(buf, sizeof buf, "gemv_generic_kernel<%s,%s>", ta, tv); return buf; }
         const int v = variant(c);
         const char *nt = c->opt_nt ? "true" : "false";
@@ -88,7 +88,7 @@ struct Impl {
     static int gemv_grid(const lam_hip_ctx *c, uint64_t nrows)
     {
         if (nrows == 0) return 0;
-        if (c->symv_active()) return (int)(c->n / kSymvRows);     // symmetric product: one per 32-row block
+        if (c->symv_active()) return symv_reduce_grid(c->n);      // symmetric product: one per 32 rows of the second pass
         return kernel_grid(c, nrows);
     }
 
@@ -109,35 +109,65 @@ struct Impl {
             hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
     }
 
-    // y = A p from the upper triangle only (lam_kernels.h, "Symmetric product")
+    // y = A p from the upper triangle only (lam_kernels.h, "Symmetric product").  The task list is built on first use:
+    // strip s (SS columns) holds rows [0, min(n, c0 + SS)), cut into runs of `tall` rows up to row 0.65 n and of `tall / 8`
+    // rows below (the launch dispatches tasks in list order and so ends on short ones); the list is ordered by first row,
+    // strips of one row block side by side.  Shapes from tools/symv2_probe (profiles/r04_symv2_probe.txt): two vectors per
+    // lane and row (8 KiB contiguous per row and workgroup) from N = 49152 on, one below; tall = 256 rows from N = 16384 on.
+    template <int NV>
+    static int launch_symv_nv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
+    {
+        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec();
+        const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
+        const uint64_t row_pitch = (n + 63) / 64 * 64;
+        if (s.symv_tasks == nullptr) {
+            uint64_t tall = 32;
+            while (tall < (uint64_t)kSymvRowsMax && tall * 64 <= n) tall *= 2;
+            const uint64_t small = tall / 8 < 8 ? 8 : tall / 8;
+            const uint64_t split = (uint64_t)(0.65 * (double)n) / kSymvRowsMax * kSymvRowsMax;
+            std::vector<SymvTask> tasks;
+            std::vector<uint32_t> slot_base(nstrips + 1, 0);
+            for (uint32_t st = 0; st < nstrips; st++) {
+                const uint64_t rows = std::min<uint64_t>(n, (uint64_t)st * SS + SS);
+                uint32_t k = 0;
+                for (uint64_t r = 0; r < rows; k++) {
+                    const uint64_t h = std::min<uint64_t>(rows - r, r < split ? tall : small);
+                    tasks.push_back({(uint32_t)r, (uint32_t)h, st, slot_base[st] + k});
+                    r += h;
+                }
+                slot_base[st + 1] = slot_base[st] + k;
+            }
+            std::stable_sort(tasks.begin(), tasks.end(), [](const SymvTask &a, const SymvTask &b) { return a.row0 < b.row0; });
+            // all four or none: a later failure must not leave the earlier buffers behind
+            DevBuf t, rp, cp, sb;
+            HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
+            HIPCHK(c, hipMalloc(&rp.p, (size_t)nstrips * row_pitch * sizeof(TA)));
+            HIPCHK(c, hipMalloc(&cp.p, tasks.size() * SS * sizeof(TA)));
+            HIPCHK(c, hipMalloc(&sb.p, slot_base.size() * sizeof(uint32_t)));
+            HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(sb.p, slot_base.data(), slot_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            // columns behind the end of the last strip's rows are never written by a task and never read by the reduction
+            HIPCHK(c, hipMemsetAsync(cp.p, 0, tasks.size() * SS * sizeof(TA), s.stream));
+            s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p; s.symv_slot_base = sb.as<uint32_t>();
+            t.p = rp.p = cp.p = sb.p = nullptr;
+            s.symv_ntasks = (int)tasks.size();
+        }
+        hipLaunchKernelGGL((symv_task_kernel<TA, NV>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
+                           (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, sc);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n)), dim3(kBlock), 0, s.stream, (const TA *)s.symv_rowpart,
+                           (const TA *)s.symv_colpart, (const uint32_t *)s.symv_slot_base, (const TA *)p, (TA *)y, partial, n, row_pitch,
+                           nstrips, sc);
+        HIPCHK(c, hipGetLastError());
+        c->n_launch += 2;
+        return 0;
+    }
+    static int symv_reduce_grid(uint64_t n) { return (int)((n + kSymvReduceRows - 1) / kSymvReduceRows); }
+    static int symv_nv(const lam_hip_ctx *c) { return c->n >= 49152 ? 2 : 1; }
     static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
     {
         if constexpr (std::is_same<TA, TV>::value) {
-            const uint64_t n = c->n;
-            const uint32_t ntiles = (uint32_t)(n / SymvShape<TA>::TILE), nblk = (uint32_t)(n / kSymvRows);
-            if (s.symv_tasks == nullptr) {
-                std::vector<SymvTask> tasks;
-                for (uint32_t I = 0; I < nblk; I++)
-                    for (uint32_t j = (uint32_t)(((uint64_t)I * kSymvRows) / SymvShape<TA>::TILE); j < ntiles; j++) tasks.push_back({I, j});
-                // all three or none: a later failure must not leave the earlier buffers behind
-                DevBuf t, rp, cp;
-                HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
-                HIPCHK(c, hipMalloc(&rp.p, (size_t)nblk * ntiles * kSymvRows * sizeof(TA)));
-                HIPCHK(c, hipMalloc(&cp.p, (size_t)nblk * n * sizeof(TA)));
-                HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
-                HIPCHK(c, hipMemsetAsync(cp.p, 0, (size_t)nblk * n * sizeof(TA), s.stream));
-                s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p;
-                t.p = rp.p = cp.p = nullptr;
-                s.symv_ntasks = (int)tasks.size();
-            }
-            hipLaunchKernelGGL((symv_task_kernel<TA>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
-                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, n, ntiles, sc);
-            HIPCHK(c, hipGetLastError());
-            hipLaunchKernelGGL((symv_reduce_kernel<TA>), dim3(nblk), dim3(kBlock), 0, s.stream, (const TA *)s.symv_rowpart,
-                               (const TA *)s.symv_colpart, (const TA *)p, (TA *)y, partial, n, ntiles, sc);
-            HIPCHK(c, hipGetLastError());
-            c->n_launch += 2;
-            return 0;
+            return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc) : launch_symv_nv<1>(c, s, p, y, partial, sc);
         } else {
             return fail(c, LAM_HIP_EINVAL, "the symmetric product needs matrix and vector of one type");
         }
@@ -288,10 +318,11 @@ void free_shard(ShardBase &s, bool keep_matrix = false)
     const size_t keepCap = keep_matrix ? s.A_capacity : 0;
     if (keep_matrix) s.A = nullptr;
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
-                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.part_aux};
+                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.symv_slot_base, s.part_aux};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = nullptr;
     s.symv_tasks = nullptr;
+    s.symv_slot_base = nullptr;
     s.symv_ntasks = 0;
     if (s.sc_host) (void)hipHostFree(s.sc_host);
     if (s.host_flags) (void)hipHostFree(s.host_flags);

@@ -652,8 +652,14 @@ def test_maximum_size_known_answer(lam):
 # ------------------------------------------------------------------------------------------------
 # option "symmetric": the product reads only the upper triangle (precondition A == A^T)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype_name,n", [("F64", 4096), ("F64", 12288), ("F32", 8192), ("F32", 16384)])
+@pytest.mark.parametrize("dtype_name,n", [("F64", 4096), ("F64", 12288), ("F32", 8192), ("F32", 16384),
+                                          # any N since round 4: odd, shorter than a strip, shorter than a vector, ragged last strip / last task
+                                          ("F64", 1), ("F64", 7), ("F64", 77), ("F64", 513), ("F64", 1000), ("F64", 4100), ("F64", 10001),
+                                          ("F32", 3), ("F32", 1025), ("F32", 5003), ("F64", 24576), ("F64", 50000)])
 def test_symmetric_product_matches_general_gemv(lam, dtype_name, n):
+    """Upper-triangle product against the general GEMV on the same (bit-symmetric) matrix, and against numpy where the matrix
+    is small enough to download: task heights 32 ... 256, one and two vectors per lane (N >= 49152), masked diagonal tasks,
+    rows that end inside a strip / a vector."""
     eps = 2.0 ** -52 if dtype_name == "F64" else 2.0 ** -24
     x = np.random.default_rng(n).uniform(-1, 1, n)
     with lam.Solver(getattr(lam, dtype_name)) as s:
@@ -670,8 +676,8 @@ def test_symmetric_product_matches_general_gemv(lam, dtype_name, n):
     assert np.max(np.abs(y1 - y0)) <= 64 * eps * np.max(np.abs(y0)) * 4
 
 
-def test_symmetric_cg_matches_general_cg(lam):
-    n = 8192
+@pytest.mark.parametrize("n", [8192, 5001])
+def test_symmetric_cg_matches_general_cg(lam, n):
     res = []
     for sym in (0, 1):
         with lam.Solver(lam.F64) as s:
@@ -687,9 +693,9 @@ def test_symmetric_cg_matches_general_cg(lam):
 
 def test_symmetric_option_preconditions(lam):
     with lam.Solver(lam.F64) as s:
-        s.generate_random_spd(4100, 5, 10.0)           # not a multiple of the tile: option has no effect
+        s.generate_random_spd(4100, 5, 10.0)           # any N (round 1 needed a multiple of 4096)
         s.set_option("symmetric", 1)
-        assert s.get_option("symmetric_effective") == 0
+        assert s.get_option("symmetric_effective") == 1
         s.generate_random_spd(4096, 5, 10.0)
         assert s.get_option("symmetric_effective") == 1
         rows = s.download_rows(7, 1)

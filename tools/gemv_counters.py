@@ -34,7 +34,8 @@ def parse_cases(text):
     cases = []
     for tok in text.split(","):
         f = tok.split(":")
-        cases.append((f[0], int(f[1]), int(f[2]) if len(f) > 2 else -1))
+        # a third field "sym": option symmetric = 1 (the upper-triangle product; its first pass, symv_task_kernel, is the row)
+        cases.append((f[0], int(f[1]), (-2 if f[2] == "sym" else int(f[2])) if len(f) > 2 else -1))
     return cases
 
 
@@ -46,7 +47,10 @@ def child(cases):
             s.generate_random_spd(n, 1234, 1e4)
             s.generate_random_rhs(1235)
             s.cg_init()
-            s.set_option("gemv_variant", v)
+            if v == -2:
+                s.set_option("symmetric", 1)
+            else:
+                s.set_option("gemv_variant", v)
             s.gemv_only(REPS)               # 1 warm-up + REPS launches
             print("case", d, n, v, s.gemv_kernel_name(), flush=True)
 
@@ -67,7 +71,7 @@ def collect(cases_text, counters, work, tag):
             dur[int(x["Dispatch_Id"])] = (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-3
     per = {}
     for x in csv.DictReader(open(cfiles[0])):
-        if "gemv_" not in x["Kernel_Name"]:
+        if "gemv_" not in x["Kernel_Name"] and "symv_task" not in x["Kernel_Name"]:
             continue
         d = per.setdefault(int(x["Dispatch_Id"]), {"kernel": x["Kernel_Name"], "vgpr": x.get("VGPR_Count") or x.get("Arch_VGPR_Count"),
                                                       "lds": x.get("LDS_Block_Size"), "grid": x.get("Grid_Size")})
@@ -86,7 +90,8 @@ def main():
     if a.child:
         return child(cases)
     work = tempfile.mkdtemp(prefix="lam_gc_")
-    table = [{"dtype": d, "n": n, "variant": v, "algorithmic_bytes": ES[d] * float(n) * n + (8.0 if d == "f64" else 4.0) * 2 * n} for d, n, v in cases]
+    table = [{"dtype": d, "n": n, "variant": v, "algorithmic_bytes": (ES[d] * float(n) * (n + 1) / 2 if v == -2 else ES[d] * float(n) * n) +
+              (8.0 if d == "f64" else 4.0) * 2 * n} for d, n, v in cases]
     try:
         for gi, group in enumerate(GROUPS):
             res, err = collect(a.cases, group, work, f"g{gi}")

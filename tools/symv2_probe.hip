@@ -1,0 +1,244 @@
+// symv2_probe -- research probe, NOT part of the product: second shape of the upper-triangle product (round 4).
+// The round-1 shape (tools/symv_probe.hip) flushed one column partial per 32 rows: 0.55 GB written + read again per product at
+// N=65536, and its row partials lived in 64 registers per lane.  Here a task is a column STRIP (the 4 KiB the workgroup's 4 waves
+// read contiguously per row: 512 fp64 / 1024 fp32 columns) times a run of rows -- 256 for most of the triangle, 32 for the rows
+// dispatched last, so that the launch ends on short tasks --; a lane keeps its column partials in registers over ALL rows of the
+// task and only 8 row partials at a time, reduced across the wave every 8 rows with a transposed butterfly (10 exchanges for 8
+// rows instead of 48) and parked in LDS until the task ends.  Partials: rowpart[strip][row] + colpart[task][column of the strip]:
+// ~0.1 GB written per product instead of 0.55.  Fixed task list, fixed orders: deterministic.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 tools/symv2_probe.hip -o tools/symv2_probe.out ; run: symv2_probe.out [N] [small_from_fraction]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../2024-eumaster4hpc-student-challenge_amd/csrc/lam_kernels.h"
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+using lam::kBlock;
+static hipStream_t g_stream = nullptr;     // SYMV2_STREAM=1: a non-blocking stream of its own (the library's way)
+
+template <typename T> struct Vec;
+template <> struct Vec<double> { typedef double t __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+template <> struct Vec<float> { typedef float t __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+
+__host__ __device__ inline uint64_t mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ void gen_sym(T *A, uint64_t n, uint64_t lda, int big_diag)
+{
+    const uint64_t total = n * lda;
+    for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = idx / lda, j = idx % lda, lo = i < j ? i : j, hi = i < j ? j : i;
+        const double u = (double)(mix(lo * n + hi) >> 11) * (1.0 / 9007199254740992.0);
+        A[idx] = j >= n ? (T)0 : (T)(i == j ? (big_diag ? 1.0 + 999999.0 * u : 2.0 + u) : (2.0 * u - 1.0) / (double)n);
+    }
+}
+template <typename T>
+__global__ void gen_vec(T *p, uint64_t n, uint64_t npad)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (uint64_t)gridDim.x * 256)
+        p[i] = i < n ? (T)(2.0 * ((double)(mix(i ^ 0xABCDEFull) >> 11) * (1.0 / 9007199254740992.0)) - 1.0) : (T)0;
+}
+
+// plain full-matrix product for the check and the comparison
+template <typename T>
+__global__ void __launch_bounds__(256) gemv_full(const T *__restrict__ A, const T *__restrict__ p, T *__restrict__ y, uint64_t n, uint64_t lda)
+{
+    using V = typename Vec<T>::t;
+    constexpr int VEC = Vec<T>::N;
+    __shared__ T s_part[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t row0 = (uint64_t)blockIdx.x * 2;
+    T acc[2] = {0, 0};
+    for (uint64_t c = ((uint64_t)wave * 64 + lane) * VEC; c < n; c += 256 * VEC) {
+        const V pv = *reinterpret_cast<const V *>(p + c);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (row0 + r >= n) continue;
+            const V a = __builtin_nontemporal_load(reinterpret_cast<const V *>(A + (row0 + r) * lda + c));
+#pragma unroll
+            for (int i = 0; i < VEC; i++) acc[r] += a[i] * pv[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        T s = acc[r];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) s_part[r][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && row0 + threadIdx.x < n)
+        y[row0 + threadIdx.x] = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]);
+}
+
+// ---- the product's kernels (lam::symv_task_kernel / lam::symv_reduce_kernel), driven with this probe's own task schedules ------------
+using lam::SymvTask;
+typedef SymvTask Task;
+constexpr int kRowsMax = lam::kSymvRowsMax;
+
+template <typename F>
+double time_once_ms(F f, int reps)
+{
+    static hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+    (void)hipEventRecord(e0, g_stream);
+    for (int i = 0; i < reps; i++) f();
+    (void)hipEventRecord(e1, g_stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+// a plan = kernel shape + task schedule; all plans share the matrix and are timed in turn, `rounds` times (the device's clock and
+// memory states drift by several percent within seconds: only interleaved measurements compare)
+template <typename T>
+struct Plan {
+    std::string name;
+    int NV;
+    std::vector<std::pair<int, double>> sched;     // task height, up to which row fraction
+    uint32_t nstrips = 0, ntasks = 0;
+    T *rowpart = nullptr, *colpart = nullptr;
+    Task *dt = nullptr;
+    uint32_t *dsb = nullptr;
+    std::vector<double> t1, t12;
+    double err = 0;
+};
+
+template <typename T>
+bool pass1(const Plan<T> &pl, const T *A, const T *p, uint64_t n, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch)
+{
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, (const lam::CgScalars *)nullptr);
+    else return false;
+    return true;
+}
+template <typename T>
+bool pass2(const Plan<T> &pl, const T *p, T *y, double *partial, uint64_t n, uint64_t row_pitch)
+{
+    const unsigned grid = (unsigned)((n + lam::kSymvReduceRows - 1) / lam::kSymvReduceRows);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (const lam::CgScalars *)nullptr);
+    else return false;
+    return true;
+}
+
+template <typename T>
+int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
+{
+    constexpr int VEC = Vec<T>::N;
+    const uint64_t align = n * sizeof(T) >= 4096 ? 4096 / sizeof(T) : 16 / sizeof(T);
+    const uint64_t lda = (n + align - 1) / align * align, ncols_vec = (n + VEC - 1) / VEC * VEC;
+    const uint64_t row_pitch = (n + 63) / 64 * 64, npad = (ncols_vec + 16383) / 16384 * 16384;
+    T *A, *p, *y, *yref; double *partial;
+    CHK(hipMalloc(&A, n * lda * sizeof(T))); CHK(hipMalloc(&p, npad * sizeof(T))); CHK(hipMalloc(&y, n * sizeof(T)));
+    CHK(hipMalloc(&yref, n * sizeof(T))); CHK(hipMalloc(&partial, ((n + 31) / 32) * 8));
+    hipLaunchKernelGGL(gen_sym<T>, dim3(8192), dim3(256), 0, 0, A, n, lda, getenv("SYMV2_GEN") ? 1 : 0);
+    hipLaunchKernelGGL(gen_vec<T>, dim3(256), dim3(256), 0, 0, p, n, npad);
+    auto full = [&] { hipLaunchKernelGGL(gemv_full<T>, dim3((unsigned)((n + 1) / 2)), dim3(256), 0, g_stream, A, p, yref, n, lda); };
+    full();
+    CHK(hipDeviceSynchronize());
+    std::vector<T> h(n), hr(n);
+    CHK(hipMemcpy(hr.data(), yref, n * sizeof(T), hipMemcpyDeviceToHost));
+    double maxref = 0;
+    for (uint64_t i = 0; i < n; i++) maxref = std::max(maxref, std::fabs((double)hr[i]));
+
+    std::vector<Plan<T>> plans;
+    for (const auto &spec : specs) {       // NV:h1@f1,h2@f2,...,hlast
+        Plan<T> pl;
+        pl.name = spec;
+        char sched[256] = "";
+        if (sscanf(spec.c_str(), "%d:%255s", &pl.NV, sched) != 2) { printf("bad spec %s\n", spec.c_str()); return 1; }
+        for (char *tok = strtok(sched, ","); tok; tok = strtok(nullptr, ",")) {
+            int hgt = 0; double f = 2.0;
+            if (sscanf(tok, "%d@%lf", &hgt, &f) < 1 || hgt % 8 || hgt > kRowsMax || hgt <= 0) { printf("bad schedule %s\n", tok); return 1; }
+            pl.sched.push_back({hgt, f});
+        }
+        const uint64_t SS = (uint64_t)pl.NV * kBlock * VEC;
+        pl.nstrips = (uint32_t)((ncols_vec + SS - 1) / SS);
+        std::vector<Task> tasks;
+        std::vector<uint32_t> slot_base(pl.nstrips + 1, 0);
+        // row boundaries of the schedule classes, aligned so that every class starts on a multiple of the largest height
+        std::vector<uint64_t> upto;
+        for (auto &c : pl.sched) upto.push_back(c.second >= 1.0 ? n : (uint64_t)(c.second * (double)n) / kRowsMax * kRowsMax);
+        for (uint32_t s = 0; s < pl.nstrips; s++) {
+            const uint64_t rows = std::min<uint64_t>(n, (uint64_t)s * SS + SS);
+            uint32_t k = 0;
+            for (uint64_t r = 0; r < rows;) {
+                size_t cls = 0;
+                while (cls + 1 < pl.sched.size() && r >= upto[cls]) cls++;
+                const uint64_t hgt = std::min<uint64_t>(rows - r, (uint64_t)pl.sched[cls].first);
+                tasks.push_back({(uint32_t)r, (uint32_t)hgt, s, slot_base[s] + k});
+                k++;
+                r += hgt;
+            }
+            slot_base[s + 1] = slot_base[s] + k;
+        }
+        // row-major: all strips of a row block run side by side (whole rows stream, like the GEMV)
+        std::stable_sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.row0 < b.row0; });
+        pl.ntasks = (uint32_t)tasks.size();
+        CHK(hipMalloc(&pl.rowpart, (size_t)pl.nstrips * row_pitch * sizeof(T))); CHK(hipMalloc(&pl.colpart, (size_t)pl.ntasks * SS * sizeof(T)));
+        CHK(hipMalloc(&pl.dt, tasks.size() * sizeof(Task))); CHK(hipMalloc(&pl.dsb, slot_base.size() * 4));
+        CHK(hipMemcpy(pl.dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
+        CHK(hipMemcpy(pl.dsb, slot_base.data(), slot_base.size() * 4, hipMemcpyHostToDevice));
+        CHK(hipMemset(pl.colpart, 0xff, (size_t)pl.ntasks * SS * sizeof(T)));     // NaNs: every slot the reduce reads must have been written
+        CHK(hipMemset(pl.rowpart, 0xff, (size_t)pl.nstrips * row_pitch * sizeof(T)));
+        if (!pass1(pl, A, p, n, lda, ncols_vec, row_pitch) || !pass2(pl, p, y, partial, n, row_pitch)) { printf("shape of %s not compiled in\n", spec.c_str()); return 1; }
+        CHK(hipDeviceSynchronize());
+        CHK(hipMemcpy(h.data(), y, n * sizeof(T), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++) {
+            if (!(h[i] == h[i])) pl.err = 1e300;
+            pl.err = std::max(pl.err, std::fabs((double)h[i] - (double)hr[i]) / maxref);
+        }
+        plans.push_back(pl);
+    }
+    std::vector<double> tf;
+    for (int r = 0; r < rounds; r++) {
+        tf.push_back(time_once_ms(full, 5));
+        for (auto &pl : plans) {
+            pl.t1.push_back(time_once_ms([&] { pass1(pl, A, p, n, lda, ncols_vec, row_pitch); }, 5));
+            pl.t12.push_back(time_once_ms([&] { pass1(pl, A, p, n, lda, ncols_vec, row_pitch); pass2(pl, p, y, partial, n, row_pitch); }, 5));
+        }
+    }
+    auto stat = [](std::vector<double> v, double *mn, double *med) { std::sort(v.begin(), v.end()); *mn = v[0]; *med = v[v.size() / 2]; };
+    const double gb_full = (double)sizeof(T) * n * n / 1e9, gb_tri = gb_full / 2 + (double)sizeof(T) * n / 2 / 1e9;
+    double mn, med;
+    stat(tf, &mn, &med);
+    printf("N=%llu %s lda=%llu, %d interleaved rounds of 5 launches; triangle = %.2f GB\n", (unsigned long long)n, sizeof(T) == 8 ? "fp64" : "fp32",
+           (unsigned long long)lda, rounds, gb_tri);
+    printf("%-44s  min %7.3f ms  median %7.3f ms  %7.1f GB/s (median, whole matrix)\n", "full product (simple 2-row kernel)", mn, med, gb_full / med * 1e3);
+    const double med_full = med;
+    int rc = 0;
+    for (auto &pl : plans) {
+        double mn1, med1, mn12, med12;
+        stat(pl.t1, &mn1, &med1); stat(pl.t12, &mn12, &med12);
+        printf("%-44s  tasks %6u  pass1 min %6.3f med %6.3f | 1+2 min %6.3f med %6.3f ms = %6.1f GB/s on the triangle, %.3fx full | err %.1e\n", pl.name.c_str(),
+               pl.ntasks, mn1, med1, mn12, med12, gb_tri / med12 * 1e3, med_full / med12, pl.err);
+        if (!(pl.err < (sizeof(T) == 8 ? 1e-12 : 1e-4))) rc = 2;
+    }
+    fflush(stdout);
+    return rc;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) { printf("usage: symv2_probe.out N f64|f32 rounds NV:h1@f1,h2@f2,...,hlast ...\n"); return 1; }
+    const uint64_t n = strtoull(argv[1], nullptr, 10);
+    const bool f32 = !strcmp(argv[2], "f32");
+    if (getenv("SYMV2_STREAM")) CHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    const int rounds = atoi(argv[3]);
+    std::vector<std::string> specs;
+    for (int i = 4; i < argc; i++) specs.push_back(argv[i]);
+    return f32 ? run<float>(n, specs, rounds) : run<double>(n, specs, rounds);
+}
