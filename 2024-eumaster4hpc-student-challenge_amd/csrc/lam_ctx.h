@@ -41,6 +41,9 @@ struct ShardBase {
     SymvTask *symv_tasks = nullptr;
     uint32_t *symv_slot_base = nullptr;   // [strips + 1]: first colpart slot of every strip
     int symv_ntasks = 0;
+    void *symv_gather = nullptr;          // several shards: P records [full-length contribution to A p | double], double-buffered
+                                          // like ap_gather in one process (symv_gather_bytes = one buffer)
+    size_t symv_gather_bytes = 0;
     double *part_gemv = nullptr; // [gemv_blocks]
     double *part_vec = nullptr;  // [vec_blocks]
     double *gather_a = nullptr;  // [kMaxShards] p.Ap partials of all shards (or the reduced scalar at [0])
@@ -161,8 +164,11 @@ struct lam_hip_ctx {
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
-    // the symmetric product exists for one shard and fp64/fp32 storage (any n)
+    // the symmetric product exists for fp64/fp32 storage (any n): one shard, or several row shards on the gather-Ap exchange
+    // (inside CG only: every shard contributes a full-length vector per iteration, lam_exchange.h)
     bool symv_active() const { return opt_symmetric && !rank_mode && total_shards == 1 && dtype != LAM_HIP_BF16 && n > 0; }
+    bool symv_multi_active() const { return opt_symmetric && dtype != LAM_HIP_BF16 && n > 0 && exchange1_ok(); }
+    uint64_t symv_stride_bytes() const { return n * esz_v() + 8; }
 
     bool exchange2_wanted() const { return (rank_mode || total_shards > 1) && opt_exchange == 2 && opt_finalize != 0; }
     // gather-Ap needs equal slices and an 8-byte aligned tail for the double (total_shards == nranks in rank mode)

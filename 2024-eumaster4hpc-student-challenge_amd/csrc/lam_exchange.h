@@ -686,17 +686,55 @@ int do_cg_init_exchange1_local(lam_hip_ctx *c)
 // The gather buffer is double (iteration parity): shard q may start GEMV k+1 -- which stores into its peers' buffers --
 // as soon as ITS update of iteration k is done, while a slower peer still reads the records of iteration k; GEMV k+2
 // cannot start before every peer has finished GEMV k+1, i.e. its update k.
+// Symmetric product on several shards (option "symmetric" on the gather-Ap exchange): the record a shard gathers is not its Ap
+// slice but its full-length CONTRIBUTION to A p (its rows' products over their cyclic half windows plus the mirrored products
+// for the columns it touched), followed by its part of p.Ap; the full-length vector step adds the P records in shard order.
+// One buffer per iteration parity like ap_gather (one process) or one (rank mode: the collective's destination).
+int ensure_symv_gather(lam_hip_ctx *c, ShardBase &s)
+{
+    const size_t one = (size_t)c->total_shards * c->symv_stride_bytes();
+    if (s.symv_gather != nullptr && s.symv_gather_bytes == one) return 0;
+    LAMCHK(set_dev(c, s));
+    if (s.symv_gather) { (void)hipFree(s.symv_gather); s.symv_gather = nullptr; }
+    HIPCHK(c, hipMalloc(&s.symv_gather, one * (c->rank_mode ? 1 : 2)));
+    s.symv_gather_bytes = one;
+    return 0;
+}
+
 int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
     return dispatch(c, [&](auto impl) -> int {
         using I = decltype(impl);
         using TV = typename ImplTraits<I>::TV;
         const int P = c->total_shards;
-        const uint64_t stride = c->ex1_stride_bytes(), base = c->ex1_base();
-        auto buf = [&](ShardBase &t) { return (char *)t.ap_gather + (size_t)(k & 1) * t.ap_gather_bytes; };
+        const bool sym = c->symv_multi_active();
+        if (sym) for (auto &s : c->sh) LAMCHK(ensure_symv_gather(c, s));
+        const uint64_t stride = sym ? c->symv_stride_bytes() : c->ex1_stride_bytes(), base = c->ex1_base();
+        auto buf = [&](ShardBase &t) {
+            return sym ? (char *)t.symv_gather + (size_t)(k & 1) * t.symv_gather_bytes : (char *)t.ap_gather + (size_t)(k & 1) * t.ap_gather_bytes;
+        };
         for (auto &s : c->sh) {
             LAMCHK(set_dev(c, s));
             const uint64_t off = (uint64_t)s.index * stride;
+            if (sym) {
+                PtrList recs, tails;
+                recs.n = tails.n = P;
+                for (auto &t : c->sh) {
+                    recs.p[t.index] = buf(t) + off;
+                    tails.p[t.index] = buf(t) + off + stride - 8;
+                }
+                const bool timed = timed_iteration(c, s, k);
+                s.split_slot[slot] = false;
+                s.timed_slot[slot] = timed;
+                if (timed) RECORD(c, s.ev_g0[slot], s.stream);
+                LAMCHK(I::launch_symv(c, s, (const TV *)s.p, nullptr, s.part_gemv, s.sc, &recs));
+                hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv,
+                                   I::symv_reduce_grid(c->n), tails, 0, (const CgScalars *)s.sc);
+                LAUNCHED(c);
+                if (timed) RECORD(c, s.ev_g1[slot], s.stream);
+                if (!(c->opt_join && &s == &c->sh[0])) RECORD(c, s.ev_a, s.stream);
+                continue;
+            }
             Finalize f = no_finalize(c);
             f.active = c->opt_finalize ? 1 : 0;
             f.slot = 0;
@@ -743,12 +781,12 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
                 // the two vector kernels in ONE launch (r.r resolved by its reducer workgroup): 2 launches per shard and iteration
                 hipLaunchKernelGGL((update_full_fused_kernel<TV>), dim3(grid + 1), dim3(kBlock), 0, s.stream, (const char *)buf(s), stride,
                                    base, P, s.sc, k, rel_error, (TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec,
-                                   grid, s.bcast, seq, c->direct_err, (volatile int *)s.host_flags);
+                                   grid, s.bcast, seq, c->direct_err, (volatile int *)s.host_flags, sym ? 1 : 0);
                 LAUNCHED(c);
                 continue;
             }
             hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)buf(s), stride,
-                               base, P, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
+                               base, P, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec, sym ? 1 : 0);
             LAUNCHED(c);
             hipLaunchKernelGGL((update_p_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc,
                                k, rel_error, (const TV *)s.r_full, (TV *)s.p, c->n, (volatile int *)s.host_flags);
@@ -791,8 +829,11 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         using TV = typename ImplTraits<I>::TV;
         ShardBase &s = c->sh[0];
         LAMCHK(set_dev(c, s));
-        const uint64_t stride = c->ex1_stride_bytes(), base = c->ex1_base();
-        char *rec = (char *)s.ap_gather + (uint64_t)c->rank * stride;
+        const bool sym = c->symv_multi_active();
+        if (sym) LAMCHK(ensure_symv_gather(c, s));
+        const uint64_t stride = sym ? c->symv_stride_bytes() : c->ex1_stride_bytes(), base = c->ex1_base();
+        char *const gathered = sym ? (char *)s.symv_gather : (char *)s.ap_gather;
+        char *rec = gathered + (uint64_t)c->rank * stride;
         // 1. GEMV straight into this rank's record; its last workgroup leaves the rank's p.Ap partial
         //    behind the slice (with option "finalize" = 0: a 1-block launch does)
         Finalize f = no_finalize(c);
@@ -802,15 +843,27 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         s.split_slot[slot] = false;
         s.timed_slot[slot] = timed;
         if (timed) RECORD(c, s.ev_g0[slot], s.stream);
+        if (sym) {
+            // the symmetric product's two passes leave this rank's full-length contribution in its record, a 1-block launch its p.Ap part
+            PtrList recs, tails;
+            recs.n = tails.n = 1;
+            recs.p[0] = rec;
+            tails.p[0] = rec + stride - 8;
+            LAMCHK(I::launch_symv(c, s, (const TV *)s.p, nullptr, s.part_gemv, s.sc, &recs));
+            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, I::symv_reduce_grid(c->n),
+                               tails, 0, (const CgScalars *)s.sc);
+            LAUNCHED(c);
+        } else {
         LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc, 0, 0, 0, &f));
+        }
         if (timed) RECORD(c, s.ev_g1[slot], s.stream);
-        if (!c->opt_finalize) {
+        if (!sym && !c->opt_finalize) {
             hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, s.gemv_blocks,
                                f.dst, 0, (const CgScalars *)s.sc);
             LAUNCHED(c);
         }
         // 2. the iteration's only collective
-        NCCLCHK(c, ncclAllGather(rec, s.ap_gather, stride, ncclChar, c->comm, s.stream));
+        NCCLCHK(c, ncclAllGather(rec, gathered, stride, ncclChar, c->comm, s.stream));
         c->n_collectives++;
         // 3. alpha, x slice, FULL r (+ partials of r.r over the full vector: no collective needed)
         const int grid = vec_grid(c->n);
@@ -818,14 +871,14 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
             // 3 + 4 in ONE launch: GEMV, collective, vector step
             const unsigned long long seq = c->seq_base + (unsigned)k;
             c->seq_span = std::max<uint64_t>(c->seq_span, (uint64_t)k + 1);
-            hipLaunchKernelGGL((update_full_fused_kernel<TV>), dim3(grid + 1), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
+            hipLaunchKernelGGL((update_full_fused_kernel<TV>), dim3(grid + 1), dim3(kBlock), 0, s.stream, (const char *)gathered, stride,
                                base, c->nranks, s.sc, k, rel_error, (TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec,
-                               grid, s.bcast, seq, c->direct_err, (volatile int *)s.host_flags);
+                               grid, s.bcast, seq, c->direct_err, (volatile int *)s.host_flags, sym ? 1 : 0);
             LAUNCHED(c);
             return 0;
         }
-        hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)s.ap_gather, stride,
-                           base, c->nranks, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec);
+        hipLaunchKernelGGL((update_xr_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const char *)gathered, stride,
+                           base, c->nranks, s.sc, k, (const TV *)s.p, (TV *)s.x, (TV *)s.r_full, c->n, s.row0, s.nrows, s.part_vec, sym ? 1 : 0);
         LAUNCHED(c);
         // 4. beta, stop test, FULL p
         hipLaunchKernelGGL((update_p_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (const double *)s.part_vec, grid, s.sc,

@@ -1143,7 +1143,7 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "hip_calls_wait")) *value = (int64_t)c->n_wait.load();
     else if (!strcmp(name, "hip_calls_setdevice")) *value = (int64_t)c->n_setdev.load();
     else if (!strcmp(name, "symmetric")) *value = c->opt_symmetric;
-    else if (!strcmp(name, "symmetric_effective")) *value = c->symv_active() ? 1 : 0;
+    else if (!strcmp(name, "symmetric_effective")) *value = (c->symv_active() || c->symv_multi_active()) ? 1 : 0;
     else if (!strcmp(name, "exchange_effective")) *value = c->cg_direct ? 2 : ((c->exchange1_ok() && !c->exchange2_wanted()) ? 1 : 0);
     else if (!strcmp(name, "panel_lo")) *value = c->opt_panel_lo;
     else if (!strcmp(name, "panel_hi")) *value = c->opt_panel_hi;

@@ -1103,10 +1103,28 @@ __device__ __forceinline__ T wave_sum8(const T (&v)[8])
     return t;
 }
 
-template <typename T, int NV>
+// Which elements a row uses.  One shard: the upper triangle (col >= row; the diagonal for the row side only).  Several row
+// shards (CYC): an upper-triangle split would leave the first shard with (2P-1)/P^2 of the work, so every row takes the CYCLIC
+// window of the (N-1)/2 columns behind its diagonal instead -- d = (col - row) mod N in [1, (N-1)/2], and for even N the antipode
+// d = N/2 for the rows of the upper half only: every pair {i, j} is covered once, every row does the same work, contiguous row
+// shards stay balanced.
+template <bool CYC>
+__device__ __forceinline__ void symv_use(uint64_t col, uint64_t grow, uint64_t n, bool *row_side, bool *col_side)
+{
+    if (!CYC) { *row_side = col >= grow; *col_side = col > grow; return; }
+    const uint64_t d = col >= grow ? col - grow : col + n - grow;
+    const bool in_window = (d >= 1 && d <= (n - 1) / 2) || ((n & 1) == 0 && d == n / 2 && grow < n / 2);
+    *row_side = d == 0 || in_window;
+    *col_side = in_window;
+}
+constexpr uint32_t kSymvInterior = 0x80000000u;   // flag in SymvTask::nrows (host: every element of the task is used by both sides,
+                                                  // the whole strip lies inside the row, a whole number of 8-row steps)
+
+template <typename T, int NV, bool CYC>
 __global__ void __launch_bounds__(kBlock)
 symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks, T *__restrict__ rowpart,
-                 T *__restrict__ colpart, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch, const CgScalars *sc)
+                 T *__restrict__ colpart, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch, uint64_t n, uint64_t row_off,
+                 const CgScalars *sc)
 {
     using MV = MatVec<T>;
     using vec_t = typename MV::vec_t;
@@ -1114,9 +1132,11 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
     __shared__ T s_rows[kWaves][kSymvRowsMax];
     if (sc != nullptr && sc->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const SymvTask t = tasks[blockIdx.x];
+    SymvTask t = tasks[blockIdx.x];                                                  // row0: LOCAL row (A, rowpart); global = row_off + row0
+    const bool interior = (t.nrows & kSymvInterior) != 0;
+    t.nrows &= ~kSymvInterior;
     const uint64_t c0 = (uint64_t)t.strip * SS, c = c0 + (uint64_t)tid * VEC;       // this lane's columns: c + v * CW + i
-    const bool masked = (uint64_t)t.row0 + t.nrows > c0;                             // the task's rows meet the strip's columns
+    const uint64_t grow0 = row_off + t.row0;
     bool live[NV];                                                                   // columns behind the row's end: nothing to do
     vec_t pc[NV];
     T cacc[NV][VEC];
@@ -1127,14 +1147,13 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
         for (int i = 0; i < VEC; i++) { pc[v][i] = (T)0; cacc[v][i] = (T)0; }
         if (live[v]) pc[v] = *reinterpret_cast<const vec_t *>(p + c + (uint64_t)v * CW);
     }
-    // Interior tasks -- whole strip inside the rows, no diagonal, a whole number of 8-row steps: nearly all of the triangle -- take
-    // the lean loop: 8 * NV unconditional loads per lane from UNIFORM row bases plus the lane's constant offset (no per-load
-    // address arithmetic, no exec-mask juggling between the loads: the predicated form below issued its loads one branch at a
-    // time and spent half of its wave cycles on issue stalls), the 8 values of p for the rows by scalar loads.
-    const bool interior = !masked && c0 + SS <= ncols_vec && (t.nrows & 7u) == 0;
+    // Interior tasks -- nearly all of them -- take the lean loop: 8 * NV unconditional loads per lane from UNIFORM row bases plus
+    // the lane's constant offset (no per-load address arithmetic, no exec-mask juggling between the loads: the predicated form
+    // below issued its loads one branch at a time and spent half of its wave cycles on issue stalls), the 8 values of p for
+    // the rows by scalar loads.
     if (interior) {
         const T *rows = A + (uint64_t)t.row0 * lda + c0;           // uniform
-        const T *prow = p + t.row0;
+        const T *prow = p + grow0;
         for (uint32_t b = 0; b < t.nrows; b += 8, rows += 8 * lda, prow += 8) {
             vec_t a[8][NV];
 #pragma unroll
@@ -1160,56 +1179,43 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
             if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
         }
     } else {
-    const T *Arow = A + (uint64_t)t.row0 * lda + c;
-    for (uint32_t b = 0; b < t.nrows; b += 8) {
-        vec_t a[8][NV];
-        T pr[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint64_t row = (uint64_t)t.row0 + b + k;
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-#pragma unroll
-                for (int i = 0; i < VEC; i++) a[k][v][i] = (T)0;
-                // masked tasks: a vector whose columns all lie left of the diagonal is not read at all
-                if (live[v] && b + k < t.nrows && (!masked || c + (uint64_t)v * CW + VEC > row))
-                    a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Arow + (uint64_t)(b + k) * lda + (uint64_t)v * CW));
-            }
-            pr[k] = b + k < t.nrows ? p[row] : (T)0;
-        }
-        T racc[8];
-        if (!masked) {
+        // tasks on the rim of a row's window (the diagonal, the far end, the antipode), ragged strips and row runs: per element
+        const T *Arow = A + (uint64_t)t.row0 * lda + c;
+        for (uint32_t b = 0; b < t.nrows; b += 8) {
+            vec_t a[8][NV];
+            T pr[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
+                const uint64_t grow = grow0 + b + k;
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) a[k][v][i] = (T)0;
+                    // one shard: a vector whose columns all lie left of the diagonal is not read at all
+                    if (live[v] && b + k < t.nrows && (CYC || c + (uint64_t)v * CW + VEC > grow))
+                        a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Arow + (uint64_t)(b + k) * lda + (uint64_t)v * CW));
+                }
+                pr[k] = b + k < t.nrows ? p[grow] : (T)0;
+            }
+            T racc[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint64_t grow = grow0 + b + k;
                 T r = (T)0;
 #pragma unroll
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
-                        cacc[v][i] = fma_tv((T)a[k][v][i], pr[k], cacc[v][i]);
+                        bool rs, cs;
+                        symv_use<CYC>(c + (uint64_t)v * CW + i, grow, n, &rs, &cs);
+                        if (rs) r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
+                        if (cs) cacc[v][i] = fma_tv((T)a[k][v][i], pr[k], cacc[v][i]);
                     }
                 racc[k] = r;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint64_t row = (uint64_t)t.row0 + b + k;
-                T r = (T)0;
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-#pragma unroll
-                    for (int i = 0; i < VEC; i++) {             // (row, col): col > row serves both, col == row once
-                        const uint64_t col = c + (uint64_t)v * CW + i;
-                        if (col >= row) r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
-                        if (col > row) cacc[v][i] = fma_tv((T)a[k][v][i], pr[k], cacc[v][i]);
-                    }
-                racc[k] = r;
-            }
+            const T tot = wave_sum8(racc);
+            if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
         }
-        const T tot = wave_sum8(racc);
-        if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
-    }
     }
 #pragma unroll
     for (int v = 0; v < NV; v++)
@@ -1224,13 +1230,17 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
         rowpart[(uint64_t)t.strip * row_pitch + t.row0 + r] = (s_rows[0][r] + s_rows[1][r]) + (s_rows[2][r] + s_rows[3][r]);
 }
 
-// 32 rows per workgroup; the terms of a row are dealt round-robin to 8 groups of 32 lanes (four loads in flight per lane)
-// and combined in a fixed order
+// Second pass.  32 entries of y per workgroup; the terms of an entry are dealt round-robin to 8 groups of 32 lanes (four loads
+// in flight per lane) and combined in a fixed order.  Row side: rowpart[s][i] of every strip s (a (strip, row) pair no task
+// covers keeps the zero it was allocated with) for the rows this shard owns, [row_off, row_off + nloc); column side: the
+// colpart slots of i's strip.  One shard: y is the product, `partial` its p.y per workgroup.  Several shards (dst.n > 0): the
+// entry is this shard's CONTRIBUTION to y[i], stored into its record in every shard's gather buffer; the consumer adds the
+// shards' records in shard order.
 template <typename T, int NV>
 __global__ void __launch_bounds__(kBlock)
 symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const uint32_t *__restrict__ slot_base,
                    const T *__restrict__ p, T *__restrict__ y, double *__restrict__ partial, uint64_t n, uint64_t row_pitch,
-                   uint32_t nstrips, const CgScalars *sc)
+                   uint32_t nstrips, uint64_t row_off, uint64_t nloc, PtrList dst, const CgScalars *sc)
 {
     constexpr int SS = NV * kBlock * MatVec<T>::N, RB = kSymvReduceRows, G = kBlock / RB;
     __shared__ T s[G][RB];
@@ -1240,15 +1250,17 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
     const uint64_t i = (uint64_t)blockIdx.x * RB + l;
     T acc = (T)0;
     if (i < n) {
-        const uint32_t s0 = (uint32_t)(i / SS);
-        uint32_t q = s0 + g;
-        for (; q + 3 * G < nstrips; q += 4 * G) {
-            const T a0 = rowpart[(uint64_t)q * row_pitch + i], a1 = rowpart[(uint64_t)(q + G) * row_pitch + i];
-            const T a2 = rowpart[(uint64_t)(q + 2 * G) * row_pitch + i], a3 = rowpart[(uint64_t)(q + 3 * G) * row_pitch + i];
-            acc += (a0 + a1) + (a2 + a3);
+        if (i >= row_off && i < row_off + nloc) {
+            const uint64_t il = i - row_off;
+            uint32_t q = g;
+            for (; q + 3 * G < nstrips; q += 4 * G) {
+                const T a0 = rowpart[(uint64_t)q * row_pitch + il], a1 = rowpart[(uint64_t)(q + G) * row_pitch + il];
+                const T a2 = rowpart[(uint64_t)(q + 2 * G) * row_pitch + il], a3 = rowpart[(uint64_t)(q + 3 * G) * row_pitch + il];
+                acc += (a0 + a1) + (a2 + a3);
+            }
+            for (; q < nstrips; q += G) acc += rowpart[(uint64_t)q * row_pitch + il];
         }
-        for (; q < nstrips; q += G) acc += rowpart[(uint64_t)q * row_pitch + i];
-        const uint32_t e = slot_base[s0 + 1];
+        const uint32_t s0 = (uint32_t)(i / SS), e = slot_base[s0 + 1];
         const uint64_t col = i - (uint64_t)s0 * SS;
         uint32_t k = slot_base[s0] + g;
         for (; k + 3 * G < e; k += 4 * G) {
@@ -1264,7 +1276,10 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
         T t = s[0][l];
 #pragma unroll
         for (int k = 1; k < G; k++) t += s[k][l];
-        if (i < n) y[i] = t;
+        if (i < n) {
+            if (dst.n == 0) y[i] = t;
+            else for (int j = 0; j < dst.n; j++) reinterpret_cast<T *>(dst.p[j])[i] = t;
+        }
         s_dot[l] = i < n ? (double)t * (double)p[i] : 0.0;
     }
     __syncthreads();
@@ -1668,24 +1683,39 @@ finalize_tail_kernel(const double *__restrict__ src, int n, char *record, uint64
     if (threadIdx.x == 0) *reinterpret_cast<double *>(record + tail_offset_bytes) = t;
 }
 
+// One element of the gathered Ap.  Gather-Ap exchange: shard i / base holds it in its record.  Symmetric product on several
+// shards (sum_records): every shard's record is a full-length CONTRIBUTION to A p; they are added in shard order (the same
+// order on every shard, so all shards keep identical r and p).
+template <typename TV>
+__device__ __forceinline__ TV gathered_ap(const char *__restrict__ gathered, uint64_t stride_bytes, uint64_t base, int nranks,
+                                          int sum_records, uint64_t i)
+{
+    if (!sum_records) {
+        const uint64_t q = i / base;
+        return reinterpret_cast<const TV *>(gathered + q * stride_bytes)[i - q * base];
+    }
+    TV v = reinterpret_cast<const TV *>(gathered)[i];
+    for (int q = 1; q < nranks; q++) v += reinterpret_cast<const TV *>(gathered + (uint64_t)q * stride_bytes)[i];
+    return v;
+}
+
 template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_xr_full_kernel(const char *__restrict__ gathered, uint64_t stride_bytes, uint64_t base, int nranks,
                       CgScalars *sc, int k, const TV *__restrict__ p_full, TV *__restrict__ x, TV *__restrict__ r_full,
-                      uint64_t n, uint64_t row0, uint64_t n_loc, double *__restrict__ partial)
+                      uint64_t n, uint64_t row0, uint64_t n_loc, double *__restrict__ partial, int sum_records)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
     double pAp = 0.0;                                   // rank order, same on every rank
     for (int q = 0; q < nranks; q++)
-        pAp += *reinterpret_cast<const double *>(gathered + (uint64_t)q * stride_bytes + base * sizeof(TV));
+        pAp += *reinterpret_cast<const double *>(gathered + (uint64_t)q * stride_bytes + stride_bytes - 8);
     const double rr = sc->rr[(k + 1) & 1];
     const double alpha_d = rr / pAp;
     const TV alpha = (TV)alpha_d;
     double acc = 0.0;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t q = i / base;
-        const TV api = reinterpret_cast<const TV *>(gathered + q * stride_bytes)[i - q * base];
+        const TV api = gathered_ap<TV>(gathered, stride_bytes, base, nranks, sum_records, i);
         const TV ri = -alpha * api + r_full[i];
         r_full[i] = ri;
         acc += (double)ri * (double)ri;
@@ -1736,7 +1766,8 @@ template <typename TV>
 __global__ void __launch_bounds__(kBlock)
 update_full_fused_kernel(const char *__restrict__ gathered, uint64_t stride_bytes, uint64_t base, int nranks, CgScalars *sc, int k,
                          double rel_error, TV *p_full, TV *__restrict__ x, TV *r_full, uint64_t n, uint64_t row0, uint64_t n_loc,
-                         double *partial, int ncompute, BcastLine *bc, unsigned long long seq, int *host_err, volatile int *host_flags)
+                         double *partial, int ncompute, BcastLine *bc, unsigned long long seq, int *host_err, volatile int *host_flags,
+                         int sum_records)
 {
     __shared__ double s_red[kWaves];
     if (sc->stop) return;
@@ -1748,7 +1779,7 @@ update_full_fused_kernel(const char *__restrict__ gathered, uint64_t stride_byte
     const int cb = (int)blockIdx.x - 1;
     double pAp = 0.0;                                   // rank order, same on every shard
     for (int q = 0; q < nranks; q++)
-        pAp += *reinterpret_cast<const double *>(gathered + (uint64_t)q * stride_bytes + base * sizeof(TV));
+        pAp += *reinterpret_cast<const double *>(gathered + (uint64_t)q * stride_bytes + stride_bytes - 8);
     const double rr = sc->rr[(k + 1) & 1];
     const double bb = sc->bb;
     const double alpha_d = rr / pAp;
@@ -1756,8 +1787,7 @@ update_full_fused_kernel(const char *__restrict__ gathered, uint64_t stride_byte
     double acc = 0.0;
     const uint64_t stride = (uint64_t)ncompute * kBlock;
     for (uint64_t i = (uint64_t)cb * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint64_t q = i / base;
-        const TV api = reinterpret_cast<const TV *>(gathered + q * stride_bytes)[i - q * base];
+        const TV api = gathered_ap<TV>(gathered, stride_bytes, base, nranks, sum_records, i);
         const TV ri = -alpha * api + r_full[i];
         r_full[i] = ri;
         acc += (double)ri * (double)ri;

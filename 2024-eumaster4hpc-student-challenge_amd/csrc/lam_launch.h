@@ -109,65 +109,117 @@ struct Impl {
             hipLaunchKernelGGL((gemv_tile_kernel<TA, TV, R, TILE, false, 4, LDS, ROT>), dim3(grid), dim3(kBlock), 0, st, a);
     }
 
-    // y = A p from the upper triangle only (lam_kernels.h, "Symmetric product").  The task list is built on first use:
-    // strip s (SS columns) holds rows [0, min(n, c0 + SS)), cut into runs of `tall` rows up to row 0.65 n and of `tall / 8`
-    // rows below (the launch dispatches tasks in list order and so ends on short ones); the list is ordered by first row,
-    // strips of one row block side by side.  Shapes from tools/symv2_probe (profiles/r04_symv2_probe.txt): two vectors per
-    // lane and row (8 KiB contiguous per row and workgroup) from N = 49152 on, one below; tall = 256 rows from N = 16384 on.
+    // y = A p reading every pair {i, j} once (lam_kernels.h, "Symmetric product").  The task list is built on first use.
+    // One shard: the upper triangle -- strip st (SS columns) holds rows [0, min(n, c0 + SS)), cut into runs of `tall` rows up to
+    // row 0.65 n and of `tall / 8` rows below (the launch dispatches tasks in list order and so ends on short ones).  Several
+    // row shards: every row of the shard takes the cyclic window of (N-1)/2 columns behind its diagonal (symv_use), i.e. the
+    // strips that window touches; runs of `tall` rows, `tall / 8` for the last 15 % of the shard's rows.  The list is ordered
+    // by first row, strips of one row run side by side (whole rows stream, as in the GEMV).  Shapes from tools/symv2_probe
+    // (profiles/r04_symv2_probe.txt): two vectors per lane and row (8 KiB contiguous per row and workgroup) from N = 49152 on,
+    // one below; one shard: tall = 256 rows from N = 16384 on; several: tall so that a shard has >= ~6000 tasks.
     template <int NV>
-    static int launch_symv_nv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
+    static int build_symv_tasks(lam_hip_ctx *c, ShardBase &s, bool cyc)
     {
+        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec(), nloc = s.nrows, R0 = s.row0;
+        const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
+        const uint64_t row_pitch = (nloc + 63) / 64 * 64, H = (n - 1) / 2;
+        uint64_t tall = cyc ? 8 : 32, split;
+        if (!cyc) {
+            while (tall < (uint64_t)kSymvRowsMax && tall * 64 <= n) tall *= 2;
+            split = (uint64_t)(0.65 * (double)n) / kSymvRowsMax * kSymvRowsMax;
+        } else {
+            const uint64_t strips_per_run = n / 2 / SS + 2;
+            while (tall < (uint64_t)kSymvRowsMax && nloc * strips_per_run / (2 * tall) >= 6000) tall *= 2;
+            split = (uint64_t)(0.85 * (double)nloc) / kSymvRowsMax * kSymvRowsMax;
+        }
+        const uint64_t small = tall / 8 < 8 ? 8 : tall / 8;
+        auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };   // closed intervals
+        std::vector<SymvTask> tasks;
+        std::vector<std::vector<SymvTask>> per_strip(nstrips);
+        for (uint64_t r = 0; r < nloc;) {
+            const uint64_t h = std::min<uint64_t>(nloc - r, r < split ? tall : small);
+            const uint64_t ga = R0 + r, gb = ga + h;                   // global rows [ga, gb)
+            for (uint32_t st = 0; st < nstrips; st++) {
+                const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;     // real columns [c0, c1]
+                bool needed, interior = c0 + SS <= ncv && h % 8 == 0;
+                if (!cyc) {
+                    needed = c1 >= ga;                                 // some column at or right of the first row's diagonal
+                    interior = interior && c0 >= gb;                   // every column right of every row
+                } else {
+                    // the union of the rows' windows (diagonal and antipode included) is the cyclic interval [ga, gb - 1 + n / 2]
+                    needed = meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2);
+                    bool in = false;
+                    for (uint64_t k = 0; k < 2; k++) {                 // the strip as it lies behind the rows, unwrapped
+                        const uint64_t u0 = c0 + k * n, u1 = c0 + SS - 1 + k * n;
+                        in = in || (u0 >= gb && u1 - ga <= H);         // 1 <= d <= (n - 1) / 2 for every row and column
+                    }
+                    interior = interior && c0 + SS <= n && in;
+                }
+                if (!needed) continue;
+                per_strip[st].push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u), st, 0});
+            }
+            r += h;
+        }
+        std::vector<uint32_t> slot_base(nstrips + 1, 0);
+        for (uint32_t st = 0; st < nstrips; st++) {
+            slot_base[st + 1] = slot_base[st] + (uint32_t)per_strip[st].size();
+            for (size_t k = 0; k < per_strip[st].size(); k++) {
+                per_strip[st][k].slot = slot_base[st] + (uint32_t)k;
+                tasks.push_back(per_strip[st][k]);
+            }
+        }
+        std::stable_sort(tasks.begin(), tasks.end(), [](const SymvTask &a, const SymvTask &b) { return a.row0 < b.row0; });
+        if (tasks.empty()) return fail(c, LAM_HIP_EINVAL, "symmetric product: no tasks");
+        // all four or none: a later failure must not leave the earlier buffers behind
+        DevBuf t, rp, cp, sb;
+        HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
+        HIPCHK(c, hipMalloc(&rp.p, (size_t)nstrips * row_pitch * sizeof(TA)));
+        HIPCHK(c, hipMalloc(&cp.p, tasks.size() * SS * sizeof(TA)));
+        HIPCHK(c, hipMalloc(&sb.p, slot_base.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(sb.p, slot_base.data(), slot_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // a (strip, row) pair no task covers keeps this zero (the second pass adds the row partials of ALL strips); columns
+        // behind the end of a ragged strip are never written by a task and never read by the second pass
+        HIPCHK(c, hipMemsetAsync(rp.p, 0, (size_t)nstrips * row_pitch * sizeof(TA), s.stream));
+        HIPCHK(c, hipMemsetAsync(cp.p, 0, tasks.size() * SS * sizeof(TA), s.stream));
+        s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p; s.symv_slot_base = sb.as<uint32_t>();
+        t.p = rp.p = cp.p = sb.p = nullptr;
+        s.symv_ntasks = (int)tasks.size();
+        return 0;
+    }
+    // the two passes.  dst.n == 0: one shard, y = A p and `partial` = the p.y partials (symv_reduce_grid(n) of them).  dst.n > 0:
+    // several shards, the shard's full-length contribution goes into dst.p[] (its record in every shard's gather buffer).
+    template <int NV>
+    static int launch_symv_nv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList &dst)
+    {
+        const bool cyc = dst.n > 0;
         const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec();
         const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
-        const uint64_t row_pitch = (n + 63) / 64 * 64;
-        if (s.symv_tasks == nullptr) {
-            uint64_t tall = 32;
-            while (tall < (uint64_t)kSymvRowsMax && tall * 64 <= n) tall *= 2;
-            const uint64_t small = tall / 8 < 8 ? 8 : tall / 8;
-            const uint64_t split = (uint64_t)(0.65 * (double)n) / kSymvRowsMax * kSymvRowsMax;
-            std::vector<SymvTask> tasks;
-            std::vector<uint32_t> slot_base(nstrips + 1, 0);
-            for (uint32_t st = 0; st < nstrips; st++) {
-                const uint64_t rows = std::min<uint64_t>(n, (uint64_t)st * SS + SS);
-                uint32_t k = 0;
-                for (uint64_t r = 0; r < rows; k++) {
-                    const uint64_t h = std::min<uint64_t>(rows - r, r < split ? tall : small);
-                    tasks.push_back({(uint32_t)r, (uint32_t)h, st, slot_base[st] + k});
-                    r += h;
-                }
-                slot_base[st + 1] = slot_base[st] + k;
-            }
-            std::stable_sort(tasks.begin(), tasks.end(), [](const SymvTask &a, const SymvTask &b) { return a.row0 < b.row0; });
-            // all four or none: a later failure must not leave the earlier buffers behind
-            DevBuf t, rp, cp, sb;
-            HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
-            HIPCHK(c, hipMalloc(&rp.p, (size_t)nstrips * row_pitch * sizeof(TA)));
-            HIPCHK(c, hipMalloc(&cp.p, tasks.size() * SS * sizeof(TA)));
-            HIPCHK(c, hipMalloc(&sb.p, slot_base.size() * sizeof(uint32_t)));
-            HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(sb.p, slot_base.data(), slot_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            // columns behind the end of the last strip's rows are never written by a task and never read by the reduction
-            HIPCHK(c, hipMemsetAsync(cp.p, 0, tasks.size() * SS * sizeof(TA), s.stream));
-            s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p; s.symv_slot_base = sb.as<uint32_t>();
-            t.p = rp.p = cp.p = sb.p = nullptr;
-            s.symv_ntasks = (int)tasks.size();
-        }
-        hipLaunchKernelGGL((symv_task_kernel<TA, NV>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
-                           (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, sc);
+        const uint64_t row_pitch = (s.nrows + 63) / 64 * 64;
+        if (s.symv_tasks == nullptr) LAMCHK(build_symv_tasks<NV>(c, s, cyc));
+        if (cyc)
+            hipLaunchKernelGGL((symv_task_kernel<TA, NV, true>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
+                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, n, s.row0, sc);
+        else
+            hipLaunchKernelGGL((symv_task_kernel<TA, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
+                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, n, s.row0, sc);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n)), dim3(kBlock), 0, s.stream, (const TA *)s.symv_rowpart,
                            (const TA *)s.symv_colpart, (const uint32_t *)s.symv_slot_base, (const TA *)p, (TA *)y, partial, n, row_pitch,
-                           nstrips, sc);
+                           nstrips, s.row0, s.nrows, dst, sc);
         HIPCHK(c, hipGetLastError());
         c->n_launch += 2;
         return 0;
     }
     static int symv_reduce_grid(uint64_t n) { return (int)((n + kSymvReduceRows - 1) / kSymvReduceRows); }
     static int symv_nv(const lam_hip_ctx *c) { return c->n >= 49152 ? 2 : 1; }
-    static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc)
+    static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList *dst = nullptr)
     {
         if constexpr (std::is_same<TA, TV>::value) {
-            return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc) : launch_symv_nv<1>(c, s, p, y, partial, sc);
+            PtrList none;
+            none.n = 0;
+            const PtrList &d = dst ? *dst : none;
+            return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc, d) : launch_symv_nv<1>(c, s, p, y, partial, sc, d);
         } else {
             return fail(c, LAM_HIP_EINVAL, "the symmetric product needs matrix and vector of one type");
         }
@@ -318,9 +370,10 @@ void free_shard(ShardBase &s, bool keep_matrix = false)
     const size_t keepCap = keep_matrix ? s.A_capacity : 0;
     if (keep_matrix) s.A = nullptr;
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
-                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.symv_slot_base, s.part_aux};
+                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.symv_slot_base, s.symv_gather, s.part_aux};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = nullptr;
+    s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = s.symv_gather = nullptr;
+    s.symv_gather_bytes = 0;
     s.symv_tasks = nullptr;
     s.symv_slot_base = nullptr;
     s.symv_ntasks = 0;

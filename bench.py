@@ -564,6 +564,12 @@ def main():
                            "(two-pass, deterministic); same system, same context; NOT the headline (different algorithm, "
                            "single GPU only)", "value": args.steps / dt_s, "ms_per_step": dt_s / args.steps * 1e3,
                    "product_ms": st_s["t_gemv"] * 1e3, "rel_residual_true": s.true_residual()}
+            # its own roofline: the triangle's bytes (s*N(N+1)/2 + the vectors) over the product's two launches
+            tri_bytes = 8.0 * n * (n + 1) / 2 + 8.0 * 2 * n
+            sym["kernel"] = s.gemv_kernel_name()
+            sym["product_gbps_on_triangle"] = tri_bytes / st_s["t_gemv"] / 1e9
+            sym["roofline_frac_on_triangle"] = sym["product_gbps_on_triangle"] / HBM_PEAK_GBPS
+            sym["algorithmic_bytes_per_product"] = tri_bytes
         except Exception as e:   # noqa: BLE001
             sys.stderr.write(f"[bench] symmetric-option side run failed: {e}\n")
         also = []

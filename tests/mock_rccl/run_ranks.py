@@ -3,7 +3,7 @@
 LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl_async.hip: stream-ordered, nothing
 synchronises hosts or streams -- the semantics of the real library).  Prints one JSON line.
 
-usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1] [--iters K] [--tol T]
+usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1] [--symmetric 0|1] [--iters K] [--tol T]
                              [--chunk C]    with mode in {tridiag, spd, file}
 --chunk C runs the solve as repeated lam_hip_cg_iterate(C) calls (the stop has to be noticed across
 calls, and every rank must leave the loop after the same call).
@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--exchange", type=int, default=0)
     ap.add_argument("--finalize", type=int, default=1)
     ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--symmetric", type=int, default=0)
     ap.add_argument("--iters", type=int, default=None)
     ap.add_argument("--tol", type=float, default=None)
     ap.add_argument("--chunk", type=int, default=0)
@@ -74,6 +75,7 @@ def main():
                 if a.finalize != 1:
                     s.set_option("finalize", a.finalize)     # 0 exists in the tuning build only
                 s.set_option("fuse_update", a.fuse)
+                s.set_option("symmetric", a.symmetric)
                 if a.quick_destroy > 0:
                     s.cg_init()
                     st = s.cg_iterate(a.quick_destroy, 0.0)
@@ -94,7 +96,8 @@ def main():
                 y = s.gemv(xprobe)               # collective
                 out[r] = dict(conv=conv, iters=s.stats["num_iters"], err=s.stats["rel_err"], x=x, res=res, y=y,
                               part=s.partition(r), ncoll=s.get_option("collectives_enqueued"), calls=calls,
-                              eff=s.get_option("exchange_effective"), fallbacks=s.get_option("direct_fallbacks"))
+                              eff=s.get_option("exchange_effective"), fallbacks=s.get_option("direct_fallbacks"),
+                              sym=s.get_option("symmetric_effective"))
         except Exception as e:                   # noqa: BLE001
             errs.append(f"rank {r}: {e!r}")
 
@@ -115,7 +118,8 @@ def main():
         "P": P, "n": n, "iters": out[0]["iters"], "converged": bool(out[0]["conv"]), "true_residual": out[0]["res"],
         "rel_err": out[0]["err"], "partition": [list(o["part"]) for o in out],
         "collectives_enqueued": [o["ncoll"] for o in out], "iterate_calls": [o["calls"] for o in out],
-        "exchange_effective": [o["eff"] for o in out], "direct_fallbacks": [o["fallbacks"] for o in out], "x_sha": hashlib.sha256(out[0]["x"].tobytes()).hexdigest(),
+        "exchange_effective": [o["eff"] for o in out], "direct_fallbacks": [o["fallbacks"] for o in out],
+        "symmetric_effective": [o["sym"] for o in out], "x_sha": hashlib.sha256(out[0]["x"].tobytes()).hexdigest(),
         "ranks_identical": bool(all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"]
                                     and o["err"] == out[0]["err"] and np.array_equal(out[0]["y"], o["y"]) for o in out)),
     }

@@ -705,7 +705,47 @@ def test_symmetric_option_preconditions(lam):
     with lam.Solver(lam.F64, n_shards=2, device_ids=[0, 0]) as s:
         s.generate_random_spd(4096, 5, 10.0)
         s.set_option("symmetric", 1)
-        assert s.get_option("symmetric_effective") == 0   # single shard only
+        assert s.get_option("symmetric_effective") == 1   # several shards: on the gather-Ap exchange (the default) ...
+        s.set_option("exchange", 0)
+        assert s.get_option("symmetric_effective") == 0   # ... not on the sliced-vector exchange
+    with lam.Solver(lam.BF16) as s:
+        s.generate_random_spd(4096, 5, 10.0)
+        s.set_option("symmetric", 1)
+        assert s.get_option("symmetric_effective") == 0   # fp64 / fp32 storage only
+
+
+@pytest.mark.parametrize("dtype_name,n,shards", [("F64", 4096, 2), ("F64", 3000, 3), ("F64", 8192, 8), ("F64", 1002, 3), ("F64", 1000, 4),
+                                                 ("F32", 4096, 4), ("F64", 12288, 4), ("F64", 49152, 8), ("F64", 64, 2), ("F64", 2050, 2)])
+def test_symmetric_product_on_several_shards(lam, dtype_name, n, shards):
+    """Option "symmetric" with several row shards in one process (gather-Ap exchange): every row takes the cyclic window of
+    (N-1)/2 columns behind its diagonal (for even N the antipode goes to the upper half's rows), so every pair {i, j} is read
+    once and contiguous row shards stay balanced; each shard contributes a full-length vector per iteration and the vector
+    step adds the shards' records in shard order.  Against the general GEMV on the same shards: same iteration count (+-1),
+    the recomputed residual (general GEMV) meets the tolerance, the solutions agree to the recursion's sensitivity; fused and
+    two-kernel vector step give the same bits; odd N / N not a multiple of the strip / wrap-around windows are in the list."""
+    dt = getattr(lam, dtype_name)
+    tol = 1e-9 if dtype_name == "F64" else 1e-5
+    res = {}
+    for label, sym, fuse in (("general", 0, 1), ("symmetric", 1, 1), ("symmetric_two_kernels", 1, 0)):
+        with lam.Solver(dt, device_ids=[0] * shards) as s:
+            s.generate_random_spd(n, 7, 200.0)
+            s.generate_random_rhs(8)
+            s.set_option("exchange", 1)
+            s.set_option("symmetric", sym)
+            s.set_option("fuse_update", fuse)
+            assert s.get_option("symmetric_effective") == sym
+            s.solve(500, tol)
+            assert s.stats["converged"] and s.get_option("exchange_effective") == 1
+            res[label] = dict(iters=s.stats["num_iters"], err=s.stats["rel_err"], x=s.solution(), res=s.true_residual())
+            s.cg_init()
+            for chunk in (1, 2, 9):
+                s.cg_iterate(chunk, 0.0)
+            res[label]["x12"] = s.solution()
+    g, y, t = res["general"], res["symmetric"], res["symmetric_two_kernels"]
+    assert abs(y["iters"] - g["iters"]) <= 1 and y["res"] <= 2 * tol + 1e-13
+    assert np.linalg.norm(y["x"] - g["x"]) / np.linalg.norm(g["x"]) <= (1e-8 if dtype_name == "F64" else 1e-3)
+    assert np.linalg.norm(y["x12"] - g["x12"]) / np.linalg.norm(g["x12"]) <= (1e-12 if dtype_name == "F64" else 1e-4)
+    assert y["iters"] == t["iters"] and y["err"] == t["err"] and np.array_equal(y["x"], t["x"]) and np.array_equal(y["x12"], t["x12"])
 
 
 @pytest.mark.parametrize("dtype_name,n,shards", [("F64", 1000, 1), ("F64", 4096, 1), ("F32", 2048, 1), ("F64", 3000, 3)])

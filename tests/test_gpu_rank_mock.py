@@ -142,6 +142,30 @@ def test_one_process_gather_ap_is_bit_identical_to_rank_mode_gather_ap(mock_asyn
         assert got == (out["iters"], out["rel_err"], out["x_sha"]), (join, got, out)
 
 
+@pytest.mark.parametrize("P,n", [(2, 1024), (4, 4096), (8, 8192), (3, 3000)])
+def test_symmetric_product_rank_mode_matches_one_process(mock_async, tmp_path, P, n):
+    """Option "symmetric" in rank mode (one process per GPU; here threads on the stream-ordered RCCL double): the iteration's one
+    collective gathers every rank's full-length contribution to A p.  Same kernels and the same summation order as one process
+    driving all shards: iteration count, residual and every bit of x agree; against the oracle and a numpy residual like every
+    multi-rank case."""
+    import hashlib
+    import importlib
+    r, out, lines = _run(mock_async, tmp_path, P, n, "spd", "--exchange", 1, "--symmetric", 1)
+    _check_mock_stats(lines, P)
+    _check_solution(out, P, n, "spd")
+    assert out["exchange_effective"] == [1] * P and out["symmetric_effective"] == [1] * P
+    lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
+    with lam.Solver(lam.F64, device_ids=[0] * P) as s:
+        s.generate_random_spd(n, 99, 200.0)          # run_ranks.py's system
+        s.generate_random_rhs(100)
+        s.set_option("exchange", 1)
+        s.set_option("symmetric", 1)
+        s.solve(2000, 1e-10)
+        assert s.get_option("symmetric_effective") == 1
+        got = (s.stats["num_iters"], s.stats["rel_err"], hashlib.sha256(s.solution().tobytes()).hexdigest())
+    assert got == (out["iters"], out["rel_err"], out["x_sha"]), (got, out)
+
+
 @pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), (4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
 def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path, P, n, mode):
     """exchange 2 sums the ranks' partial dot products with the same reduction tree as exchange 0, so the

@@ -119,8 +119,8 @@ struct Plan {
 template <typename T>
 bool pass1(const Plan<T> &pl, const T *A, const T *p, uint64_t n, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch)
 {
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, (const lam::CgScalars *)nullptr);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, false>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, false>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -128,8 +128,10 @@ template <typename T>
 bool pass2(const Plan<T> &pl, const T *p, T *y, double *partial, uint64_t n, uint64_t row_pitch)
 {
     const unsigned grid = (unsigned)((n + lam::kSymvReduceRows - 1) / lam::kSymvReduceRows);
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (const lam::CgScalars *)nullptr);
+    lam::PtrList none;
+    none.n = 0;
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -179,7 +181,8 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
                 size_t cls = 0;
                 while (cls + 1 < pl.sched.size() && r >= upto[cls]) cls++;
                 const uint64_t hgt = std::min<uint64_t>(rows - r, (uint64_t)pl.sched[cls].first);
-                tasks.push_back({(uint32_t)r, (uint32_t)hgt, s, slot_base[s] + k});
+                const bool interior = (uint64_t)s * SS + SS <= ncols_vec && hgt % 8 == 0 && (uint64_t)s * SS >= r + hgt;   // as the library
+                tasks.push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), s, slot_base[s] + k});
                 k++;
                 r += hgt;
             }
@@ -193,7 +196,7 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
         CHK(hipMemcpy(pl.dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
         CHK(hipMemcpy(pl.dsb, slot_base.data(), slot_base.size() * 4, hipMemcpyHostToDevice));
         CHK(hipMemset(pl.colpart, 0xff, (size_t)pl.ntasks * SS * sizeof(T)));     // NaNs: every slot the reduce reads must have been written
-        CHK(hipMemset(pl.rowpart, 0xff, (size_t)pl.nstrips * row_pitch * sizeof(T)));
+        CHK(hipMemset(pl.rowpart, 0, (size_t)pl.nstrips * row_pitch * sizeof(T)));       // (strip, row) pairs no task covers stay zero
         if (!pass1(pl, A, p, n, lda, ncols_vec, row_pitch) || !pass2(pl, p, y, partial, n, row_pitch)) { printf("shape of %s not compiled in\n", spec.c_str()); return 1; }
         CHK(hipDeviceSynchronize());
         CHK(hipMemcpy(h.data(), y, n * sizeof(T), hipMemcpyDeviceToHost));
