@@ -330,7 +330,7 @@ def _check_bench_line(r, nproc):
     assert out["metric"] == "cg_iterations_per_sec" and out["value"] > 0
     modes = {k: v for k, v in out["exchange_modes"].items() if k != "default"}
     assert set(modes) == {"allgather_x2+allgather_p", "allgather_x2+allgather_p, no overlap", "allgather_Ap",
-                          "direct_mailboxes", "direct_mailboxes, no split"}
+                          "allgather_Ap + symmetric product (option, not the headline)", "direct_mailboxes", "direct_mailboxes, no split"}
     for m in modes.values():
         assert m.get("value", 0) > 0 and "error" not in m, out["exchange_modes"]
     # the headline is the product's DEFAULT exchange, whatever the others measured (never a minimum over variants)
@@ -444,11 +444,12 @@ def test_bench_one_process_topology_records_every_exchange(tmp_path, gpus):
     assert out["n_gpus"] == gpus and out["value"] > 0 and out["self_check"]["passed"] and out["self_check"]["vs_one_gpu"] < 1e-9
     assert out["exchange_effective"] == 1
     modes = {k: v for k, v in out["exchange_modes"].items() if k != "default"}
-    assert len(modes) == 5, list(modes)
+    assert len(modes) == 6, list(modes)      # five exchanges + the symmetric product on the default one
     assert out["exchange_modes"]["default"].startswith("gather_Ap") and out["value"] == modes[out["exchange_modes"]["default"]]["value"]
     for name, m in modes.items():
         assert "error" not in m and m["value"] > 0, (name, m)
-        assert m["vs_one_gpu"] < 1e-9 and abs(m["rel_residual_true"] / m["rel_residual_recursive"] - 1) < 1e-6, (name, m)
+        # the symmetric product is another algorithm (other rounding): the one-GPU gate is 1e-6 there, 1e-9 for the exchanges
+        assert m["vs_one_gpu"] < (1e-6 if "symmetric" in name else 1e-9) and abs(m["rel_residual_true"] / m["rel_residual_recursive"] - 1) < 1e-6, (name, m)
     hosts = {k: v["host_enqueue_us_per_step"] for k, v in modes.items() if "host_enqueue_us_per_step" in v}
-    assert len(hosts) == 5 and all(0 < h < 2000 for h in hosts.values()), hosts
+    assert len(hosts) == 6 and all(0 < h < 2000 for h in hosts.values()), hosts
     assert "1 process" in out["config"]["parallelism"]
