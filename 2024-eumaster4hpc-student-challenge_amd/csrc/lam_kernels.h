@@ -6,7 +6,8 @@
 //   and the CPU members dot/axpby/gemv, LAM/src/CPU/ConjugateGradient_CPU_MPI_OMP.hpp:446-508.
 //
 // Design:
-//   * one CG iteration = 3 launches on a shard (2 where update_fused_kernel applies: one shard, direct exchange):
+//   * one CG iteration = 3 launches on a shard, 2 where the vector step is fused into one launch -- update_fused_kernel (one
+//     shard, direct exchange), update_full_fused_kernel (gather-Ap exchange: the multi-shard default of one process) --:
 //       gemv_coop_kernel   Ap_loc = A_loc p          (+ per-workgroup partials of p.Ap)
 //       update_xr_kernel   alpha = rr/(p.Ap); x += alpha p; r -= alpha Ap   (+ partials of r.r)
 //       update_p_kernel    rr' = r.r; beta = rr'/rr; stop test; p_slice = r + beta p  (stored into
@@ -23,8 +24,9 @@
 //     variants; gemv_generic_kernel handles any N / alignment; gemv_mfma_bf16_kernel is the MFMA
 //     experiment (slower, kept for the record).  A launch can cover one or two column panels and
 //     accumulate, which is how the rank mode overlaps the all-gather of p with its own-slice panel.
-//   * the *_full_kernel pair implements the single-collective exchange (all-gather of Ap) of the rank
-//     mode; symv_*_kernel implement the opt-in symmetric product (upper triangle only).
+//   * the *_full_kernel family implements the single-exchange iteration (gather of Ap, full-length r and p on every shard);
+//     symv_*_kernel implement the opt-in symmetric product (every pair {i, j} read once: the upper triangle on one shard,
+//     cyclic half windows on several row shards).
 #pragma once
 
 #include <hip/hip_runtime.h>

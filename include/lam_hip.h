@@ -251,18 +251,23 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   0's stream: it waits for the other shards' posts and records ONE join event they wait for -- 2(P-1)+1
  *                   runtime calls, two event hops on the device; 0 = every stream waits for every other one -- P(P-1) calls,
  *                   one hop.  Same bits.
- *   "symmetric"     single shard, fp64/fp32, N a multiple of 4096 (fp64) / 8192 (fp32): 1 = the matrix-vector
- *                   product reads only the upper triangle (A must equal its transpose, which CG requires
- *                   anyway; lam_hip_check_symmetry verifies it) -- about half the HBM traffic per iteration.
- *                   0 (default) = the reference's general row-partitioned GEMV.  "symmetric_effective" tells
- *                   whether the current context can use it.
+ *   "symmetric"     fp64/fp32 storage, any N: the matrix-vector product reads every pair {A[i][j], A[j][i]} ONCE (A must equal
+ *                   its transpose, which CG requires anyway; lam_hip_check_symmetry verifies it) -- half the HBM traffic per
+ *                   iteration, 1.7-1.8x the iteration rate at N >= 20000 on one GPU.  One shard: the upper triangle.  Several row
+ *                   shards (either multi-GPU topology, on exchange 1, inside CG): every row takes the cyclic window of (N-1)/2
+ *                   columns behind its diagonal, so contiguous row shards stay balanced, and each shard contributes a full-length
+ *                   vector to the iteration's exchange.  1 = where it pays (N >= 6144; below, the fixed cost of its two passes
+ *                   outweighs the halved stream), 2 = at every size, 0 (default) = the reference's general row-partitioned
+ *                   GEMV.  Same results to rounding (another summation order).  "symmetric_effective" tells whether the current
+ *                   context uses it.
  *   "finalize"      several shards: 1 (default) = the last workgroup of the GEMV / update kernel reduces the
  *                   shard's partial dot product inside the launch (3 launches per iteration for any shard
  *                   count); 0 = separate 1-workgroup reduction launches (5 per iteration; the round-1 chain, kept for A/B
  *                   measurements: TUNING BUILD ONLY, the product library refuses it).
- *   "fuse_update"   one shard, and exchange 2: 1 (default) = the x, r and p updates of an iteration are ONE launch (the
- *                   r.r total is handed over inside the launch); with exchange 2 and overlap 0 that launch also waits
- *                   for the peers' p slices, so an iteration is two launches.  0 = two kernels.  Same bits either way.
+ *   "fuse_update"   one shard, exchange 1 and exchange 2: 1 (default) = the x, r and p updates of an iteration are ONE launch
+ *                   (the r.r total is handed over inside the launch): an iteration is two launches per shard -- GEMV + vector
+ *                   step; with exchange 2 and overlap 0 that launch also waits for the peers' p slices.  0 = two kernels.
+ *                   Same bits either way.
  *                   The fused launch's workgroups wait for each other, so it is used only when cg_init finds that
  *                   the whole grid can be resident at once (occupancy x CU count; "fuse_effective" tells,
  *                   "assume_cus" overrides the CU count for tests); otherwise the two-kernel form runs.

@@ -3,7 +3,7 @@
 LD_PRELOADed in front of librccl.so (tests/mock_rccl/mock_rccl_async.hip: stream-ordered, nothing
 synchronises hosts or streams -- the semantics of the real library).  Prints one JSON line.
 
-usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1] [--symmetric 0|1] [--iters K] [--tol T]
+usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1] [--symmetric 0|1|2] [--iters K] [--tol T]
                              [--chunk C]    with mode in {tridiag, spd, file}
 --chunk C runs the solve as repeated lam_hip_cg_iterate(C) calls (the stop has to be noticed across
 calls, and every rank must leave the loop after the same call).

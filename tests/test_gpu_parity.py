@@ -666,7 +666,7 @@ def test_symmetric_product_matches_general_gemv(lam, dtype_name, n):
         s.generate_random_spd(n, 31, 50.0)
         assert s.check_symmetry() == 0.0
         y0 = s.gemv(x).astype(np.float64)
-        s.set_option("symmetric", 1)
+        s.set_option("symmetric", 2)                  # 2 = at every size (1 = only where it pays, N >= 6144)
         assert s.get_option("symmetric_effective") == 1
         y1 = s.gemv(x).astype(np.float64)
         A = s.download_rows(0, n).astype(np.float64) if n <= 4096 else None
@@ -683,7 +683,7 @@ def test_symmetric_cg_matches_general_cg(lam, n):
         with lam.Solver(lam.F64) as s:
             s.generate_random_spd(n, 5, 1e3)
             s.generate_random_rhs(6)
-            s.set_option("symmetric", sym)
+            s.set_option("symmetric", 2 * sym)
             conv = s.solve(2000, 1e-10)
             res.append((conv, s.stats["num_iters"], s.solution(), s.true_residual()))   # true residual: general GEMV
     (c0, k0, x0, t0), (c1, k1, x1, t1) = res
@@ -693,9 +693,12 @@ def test_symmetric_cg_matches_general_cg(lam, n):
 
 def test_symmetric_option_preconditions(lam):
     with lam.Solver(lam.F64) as s:
-        s.generate_random_spd(4100, 5, 10.0)           # any N (round 1 needed a multiple of 4096)
+        s.generate_random_spd(4100, 5, 10.0)           # any N (round 1 needed a multiple of 4096) ...
         s.set_option("symmetric", 1)
+        assert s.get_option("symmetric_effective") == 0   # ... but value 1 means "where it pays": N >= 6144
+        s.generate_random_spd(6150, 5, 10.0)
         assert s.get_option("symmetric_effective") == 1
+        s.set_option("symmetric", 2)                      # value 2: at every size
         s.generate_random_spd(4096, 5, 10.0)
         assert s.get_option("symmetric_effective") == 1
         rows = s.download_rows(7, 1)
@@ -704,13 +707,13 @@ def test_symmetric_option_preconditions(lam):
         assert abs(s.check_symmetry() - 0.25) < 1e-12
     with lam.Solver(lam.F64, n_shards=2, device_ids=[0, 0]) as s:
         s.generate_random_spd(4096, 5, 10.0)
-        s.set_option("symmetric", 1)
+        s.set_option("symmetric", 2)
         assert s.get_option("symmetric_effective") == 1   # several shards: on the gather-Ap exchange (the default) ...
         s.set_option("exchange", 0)
         assert s.get_option("symmetric_effective") == 0   # ... not on the sliced-vector exchange
     with lam.Solver(lam.BF16) as s:
         s.generate_random_spd(4096, 5, 10.0)
-        s.set_option("symmetric", 1)
+        s.set_option("symmetric", 2)
         assert s.get_option("symmetric_effective") == 0   # fp64 / fp32 storage only
 
 
@@ -731,7 +734,7 @@ def test_symmetric_product_on_several_shards(lam, dtype_name, n, shards):
             s.generate_random_spd(n, 7, 200.0)
             s.generate_random_rhs(8)
             s.set_option("exchange", 1)
-            s.set_option("symmetric", sym)
+            s.set_option("symmetric", 2 * sym)
             s.set_option("fuse_update", fuse)
             assert s.get_option("symmetric_effective") == sym
             s.solve(500, tol)
@@ -928,7 +931,7 @@ def test_changing_the_product_kernel_needs_a_new_cg_init(lam):
         s.generate_random_rhs(6)
         s.cg_init()
         s.cg_iterate(3, 0.0)
-        for opt, val in (("symmetric", 1), ("symmetric", 0), ("fuse_update", 0)):
+        for opt, val in (("symmetric", 2), ("symmetric", 0), ("fuse_update", 0)):
             s.set_option(opt, val)
             with pytest.raises(lam.LamHipError):
                 s.cg_iterate(1, 0.0)

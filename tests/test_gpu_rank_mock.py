@@ -150,7 +150,7 @@ def test_symmetric_product_rank_mode_matches_one_process(mock_async, tmp_path, P
     multi-rank case."""
     import hashlib
     import importlib
-    r, out, lines = _run(mock_async, tmp_path, P, n, "spd", "--exchange", 1, "--symmetric", 1)
+    r, out, lines = _run(mock_async, tmp_path, P, n, "spd", "--exchange", 1, "--symmetric", 2)
     _check_mock_stats(lines, P)
     _check_solution(out, P, n, "spd")
     assert out["exchange_effective"] == [1] * P and out["symmetric_effective"] == [1] * P
@@ -159,7 +159,7 @@ def test_symmetric_product_rank_mode_matches_one_process(mock_async, tmp_path, P
         s.generate_random_spd(n, 99, 200.0)          # run_ranks.py's system
         s.generate_random_rhs(100)
         s.set_option("exchange", 1)
-        s.set_option("symmetric", 1)
+        s.set_option("symmetric", 2)
         s.solve(2000, 1e-10)
         assert s.get_option("symmetric_effective") == 1
         got = (s.stats["num_iters"], s.stats["rel_err"], hashlib.sha256(s.solution().tobytes()).hexdigest())

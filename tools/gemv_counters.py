@@ -48,7 +48,7 @@ def child(cases):
             s.generate_random_rhs(1235)
             s.cg_init()
             if v == -2:
-                s.set_option("symmetric", 1)
+                s.set_option("symmetric", 2)
             else:
                 s.set_option("gemv_variant", v)
             s.gemv_only(REPS)               # 1 warm-up + REPS launches

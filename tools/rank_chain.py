@@ -21,10 +21,11 @@ def main():
         s.generate_random_spd(n, 11, 1e6)
         s.generate_random_rhs(12)
         print(f"rccl version {lam.rccl_version()}  N={n}  kernel {s.gemv_kernel_name()}")
-        for exchange, finalize, overlap, fuse in ((0, 0, 1, 0), (0, 1, 1, 0), (0, 1, 0, 0), (1, 0, 1, 0), (1, 1, 1, 0),
-                                                  (2, 1, 1, 0), (2, 1, 0, 0), (2, 1, 1, 1), (2, 1, 0, 1)):
+        for exchange, finalize, overlap, fuse, sym in ((0, 0, 1, 0, 0), (0, 1, 1, 0, 0), (0, 1, 0, 0, 0), (1, 0, 1, 0, 0), (1, 1, 1, 0, 0), (1, 1, 1, 1, 0),
+                                                       (2, 1, 1, 0, 0), (2, 1, 0, 0, 0), (2, 1, 1, 1, 0), (2, 1, 0, 1, 0), (1, 1, 1, 1, 1)):
             s.set_option("exchange", exchange); s.set_option("finalize", finalize); s.set_option("overlap", overlap)
             s.set_option("fuse_update", fuse)
+            s.set_option("symmetric", sym)      # 1: the symmetric product on the rank-mode path (cyclic half windows; here one rank = the whole matrix)
             best = None
             for _ in range(3):
                 s.cg_init()
@@ -32,8 +33,9 @@ def main():
                 st = s.cg_iterate(iters, 0.0)
                 if best is None or st["t_iter"] < best["t_iter"]:
                     best = st
-            print(f"exchange={exchange} finalize={finalize} overlap={overlap} fuse={fuse}: {best['t_iter']*1e3:.4f} ms/iter, gemv {best['t_gemv']*1e3:.4f} ms, "
+            print(f"exchange={exchange} finalize={finalize} overlap={overlap} fuse={fuse} symmetric={sym}: {best['t_iter']*1e3:.4f} ms/iter, gemv {best['t_gemv']*1e3:.4f} ms, "
                   f"other {(best['t_iter']-best['t_gemv'])*1e6:.1f} us", flush=True)
+        s.set_option("symmetric", 0)
     # single-shard chain (no RCCL) for reference
     os.environ.pop("LAM_HIP_FORCE_RCCL")
     with lam.Solver(lam.F64) as s:

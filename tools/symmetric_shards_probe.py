@@ -15,7 +15,7 @@ for n in [int(a) for a in sys.argv[1:]] or [65536, 32768]:
             res = {}
             for rnd in range(3):
                 for sym in (0, 1):
-                    s.set_option("symmetric", sym)
+                    s.set_option("symmetric", 2 * sym)
                     assert s.get_option("symmetric_effective") == sym
                     s.cg_init(); s.cg_iterate(5, 0.0)
                     l0 = s.get_option("hip_calls_launch")
