@@ -25,8 +25,19 @@ int64_t exchange_from_env(int64_t dflt)
     return (v >= 0 && v <= 2) ? v : dflt;
 }
 
+// Environment LAM_HIP_SYMMETRIC = 1 | 2: option "symmetric" of new contexts (the reference's drivers compile unchanged against
+// these headers and have no other way to ask for it).  The caller vouches for A = A^T, as CG itself does.
+int64_t symmetric_from_env(int64_t dflt)
+{
+    const char *v = getenv("LAM_HIP_SYMMETRIC");
+    if (v == nullptr || *v == '\0') return dflt;
+    const int k = atoi(v);
+    return (k >= 0 && k <= 2) ? k : dflt;
+}
+
 int create_common(lam_hip_ctx *c)
 {
+    c->opt_symmetric = symmetric_from_env(c->opt_symmetric);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

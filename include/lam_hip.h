@@ -259,7 +259,7 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   vector to the iteration's exchange.  1 = where it pays (N >= 6144; below, the fixed cost of its two passes
  *                   outweighs the halved stream), 2 = at every size, 0 (default) = the reference's general row-partitioned
  *                   GEMV.  Same results to rounding (another summation order).  "symmetric_effective" tells whether the current
- *                   context uses it.
+ *                   context uses it.  Environment LAM_HIP_SYMMETRIC = 1 | 2 sets it for new contexts (drivers).
  *   "finalize"      several shards: 1 (default) = the last workgroup of the GEMV / update kernel reduces the
  *                   shard's partial dot product inside the launch (3 launches per iteration for any shard
  *                   count); 0 = separate 1-workgroup reduction launches (5 per iteration; the round-1 chain, kept for A/B

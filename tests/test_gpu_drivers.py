@@ -69,7 +69,10 @@ def test_getopt_driver_file_mode_against_golden_solution(golden, oracle, tmp_pat
                                      (MULTI_EXE, {"LAM_NUM_SHARDS": "4", "LAM_HIP_EXCHANGE": "2", "LAM_HIP_EXPERIMENTAL_DIRECT": "1",
                                                   "LAM_HIP_DIRECT_SAME_DEVICE": "1", "GPU_MAX_HW_QUEUES": "12"}),
                                      # ... and on the three-join event exchange (the default is gather-Ap)
-                                     (MULTI_EXE, {"LAM_NUM_SHARDS": "2", "LAM_HIP_EXCHANGE": "0"})])
+                                     (MULTI_EXE, {"LAM_NUM_SHARDS": "2", "LAM_HIP_EXCHANGE": "0"}),
+                                     # option "symmetric" from the environment (the drivers have no flag for it): one shard -- the
+                                     # upper triangle --, and row shards -- cyclic half windows on the gather-Ap exchange
+                                     (ONE_EXE, {"LAM_HIP_SYMMETRIC": "2"}), (MULTI_EXE, {"LAM_NUM_SHARDS": "2", "LAM_HIP_SYMMETRIC": "2"})])
 def test_positional_drivers(golden, oracle, tmp_path, exe, env):
     """matrix rhs sol max_iters rel_error; prints the reference's 'Converged in K iterations' line."""
     for g in golden["file_mode"]:
