@@ -88,6 +88,32 @@ using lam::SymvTask;
 typedef SymvTask Task;
 constexpr int kRowsMax = lam::kSymvRowsMax;
 
+// the same tasks, the same loads, no arithmetic to speak of: what the ACCESS PATTERN alone reaches (SYMV2_READONLY=1 adds it to the table)
+template <typename T, int NV>
+__global__ void __launch_bounds__(kBlock)
+pattern_read_kernel(const T *__restrict__ A, const Task *__restrict__ tasks, T *__restrict__ sink, uint64_t lda)
+{
+    using V = typename Vec<T>::t;
+    constexpr int VEC = Vec<T>::N, CW = kBlock * VEC, SS = NV * CW;
+    Task t = tasks[blockIdx.x];
+    t.nrows &= ~lam::kSymvInterior;
+    const T *rows = A + (uint64_t)t.row0 * lda + (uint64_t)t.strip * SS;
+    T acc = (T)0;
+    for (uint32_t b = 0; b + 8 <= t.nrows; b += 8, rows += 8 * lda) {
+        V a[8][NV];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+                a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const V *>(rows + (uint64_t)k * lda + v * CW) + threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int v = 0; v < NV; v++) acc += a[k][v][0];
+    }
+    if (acc == (T)123.456) sink[0] = acc;
+}
+
 template <typename F>
 double time_once_ms(F f, int reps)
 {
@@ -212,6 +238,18 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
         for (auto &pl : plans) {
             pl.t1.push_back(time_once_ms([&] { pass1(pl, A, p, n, lda, ncols_vec, row_pitch); }, 5));
             pl.t12.push_back(time_once_ms([&] { pass1(pl, A, p, n, lda, ncols_vec, row_pitch); pass2(pl, p, y, partial, n, row_pitch); }, 5));
+        }
+    }
+    if (getenv("SYMV2_READONLY")) {
+        for (auto &pl : plans) {
+            std::vector<double> t;
+            auto f = [&] {
+                if (pl.NV == 1) hipLaunchKernelGGL((pattern_read_kernel<T, 1>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, pl.dt, y, lda);
+                else hipLaunchKernelGGL((pattern_read_kernel<T, 2>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, pl.dt, y, lda);
+            };
+            for (int r = 0; r < rounds; r++) t.push_back(time_once_ms(f, 5));
+            std::sort(t.begin(), t.end());
+            printf("%-44s  the tasks' loads alone (no arithmetic): min %6.3f med %6.3f ms\n", pl.name.c_str(), t[0], t[t.size() / 2]);
         }
     }
     auto stat = [](std::vector<double> v, double *mn, double *med) { std::sort(v.begin(), v.end()); *mn = v[0]; *med = v[v.size() / 2]; };
