@@ -1037,7 +1037,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
 // HBM roofline of the plain GEMV.  Two passes (round 4: second shape; the round-1 shape flushed a column
 // partial per 32 rows -- 0.55 GB written and read again per product -- and kept 32 row partials per lane):
 //   symv_task_kernel    one workgroup per TASK = a column strip (NV x 4 KiB per row, read contiguously by the
-//                       4 waves: 512 / 1024 fp64 columns, twice that in fp32) x a run of rows (256 for most
+//                       4 waves; the product uses NV = 1: 512 fp64 / 1024 fp32 columns) x a run of rows (256 for most
 //                       of the triangle, 32 for the rows dispatched last, so that the launch ends on short
 //                       tasks; shorter runs for small N).  A lane keeps the column partials of its columns in
 //                       registers over ALL rows of the task and 8 row partials at a time: every 8 rows they
@@ -1149,33 +1149,66 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
         for (int i = 0; i < VEC; i++) { pc[v][i] = (T)0; cacc[v][i] = (T)0; }
         if (live[v]) pc[v] = *reinterpret_cast<const vec_t *>(p + c + (uint64_t)v * CW);
     }
-    // Interior tasks -- nearly all of them -- take the lean loop: 8 * NV unconditional loads per lane from UNIFORM row bases plus
-    // the lane's constant offset (no per-load address arithmetic, no exec-mask juggling between the loads: the predicated form
-    // below issued its loads one branch at a time and spent half of its wave cycles on issue stalls), the 8 values of p for
-    // the rows by scalar loads.
+    // Interior tasks -- nearly all of them -- take the lean loop: unconditional loads from UNIFORM row bases plus the lane's
+    // constant offset (no exec-mask juggling between the loads: the predicated form below issued its loads one branch at a time
+    // and spent half of its wave cycles on issue stalls), the rows' values of p by scalar loads; software-pipelined in two halves
+    // of 4 rows -- the loads of the next step's half are issued as soon as this step's half has been consumed, so a wave always
+    // has 4 * NV ... 8 * NV loads in flight (a loop that drains its loads, computes its ~125 vector instructions and only then
+    // issues the next ones measured 1-4 % slower, profiles/r04_symv2_probe.txt).
     if (interior) {
         const T *rows = A + (uint64_t)t.row0 * lda + c0;           // uniform
         const T *prow = p + grow0;
-        for (uint32_t b = 0; b < t.nrows; b += 8, rows += 8 * lda, prow += 8) {
-            vec_t a[8][NV];
+        vec_t a0[4][NV], a1[4][NV];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int v = 0; v < NV; v++)
-                    a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)k * lda + v * CW) + tid);
+            for (int v = 0; v < NV; v++) {
+                a0[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)k * lda + v * CW) + tid);
+                a1[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)(k + 4) * lda + v * CW) + tid);
+            }
+        for (uint32_t b = 0; b < t.nrows; b += 8, prow += 8) {
+            rows += 8 * lda;
+            const bool more = b + 8 < t.nrows;
             T racc[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 4; k++) {
                 const T pr = prow[k];
                 T r = (T)0;
 #pragma unroll
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
-                        cacc[v][i] = fma_tv((T)a[k][v][i], pr, cacc[v][i]);
+                        r = fma_tv((T)a0[k][v][i], (T)pc[v][i], r);
+                        cacc[v][i] = fma_tv((T)a0[k][v][i], pr, cacc[v][i]);
                     }
                 racc[k] = r;
+            }
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+                        a0[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)k * lda + v * CW) + tid);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const T pr = prow[4 + k];
+                T r = (T)0;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) {
+                        r = fma_tv((T)a1[k][v][i], (T)pc[v][i], r);
+                        cacc[v][i] = fma_tv((T)a1[k][v][i], pr, cacc[v][i]);
+                    }
+                racc[4 + k] = r;
+            }
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+                        a1[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)(k + 4) * lda + v * CW) + tid);
             }
             const T tot = wave_sum8(racc);
             if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;

@@ -115,8 +115,8 @@ struct Impl {
     // row shards: every row of the shard takes the cyclic window of (N-1)/2 columns behind its diagonal (symv_use), i.e. the
     // strips that window touches; runs of `tall` rows, `tall / 8` for the last 15 % of the shard's rows.  The list is ordered
     // by first row, strips of one row run side by side (whole rows stream, as in the GEMV).  Shapes from tools/symv2_probe
-    // (profiles/r04_symv2_probe.txt): two vectors per lane and row (8 KiB contiguous per row and workgroup) from N = 49152 on,
-    // one below; one shard: tall = 256 rows from N = 16384 on; several: tall so that a shard has >= ~6000 tasks.
+    // (profiles/r04_symv2_probe.txt): one 16-byte vector per lane and row (a 4-KiB strip per workgroup); one shard: tall = 256
+    // rows from N = 16384 on; several: tall so that a shard has >= ~6000 tasks.
     template <int NV>
     static int build_symv_tasks(lam_hip_ctx *c, ShardBase &s, bool cyc)
     {
@@ -212,7 +212,9 @@ struct Impl {
         return 0;
     }
     static int symv_reduce_grid(uint64_t n) { return (int)((n + kSymvReduceRows - 1) / kSymvReduceRows); }
-    static int symv_nv(const lam_hip_ctx *c) { return c->n >= 49152 ? 2 : 1; }
+    // vectors per lane and row: one everywhere -- with the pipelined interior loop one 4-KiB strip per workgroup runs level with
+    // two at N = 65536 (fp64) / 131072 (fp32) and 2-5 % ahead at N <= 40000 (profiles/r04_symv2_probe.txt); two stays compiled
+    static int symv_nv(const lam_hip_ctx *) { return 1; }
     static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList *dst = nullptr)
     {
         if constexpr (std::is_same<TA, TV>::value) {
