@@ -24,7 +24,8 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 using lam::kBlock;
-static hipStream_t g_stream = nullptr;     // SYMV2_STREAM=1: a non-blocking stream of its own (the library's way)
+static hipStream_t g_stream = nullptr;
+static uint64_t g_shard_q = 0, g_shard_P = 0;   // SYMV2_SHARD=q/P: time ONE row shard of a P-way split (cyclic half windows, the library's multi-shard form)     // SYMV2_STREAM=1: a non-blocking stream of its own (the library's way)
 
 template <typename T> struct Vec;
 template <> struct Vec<double> { typedef double t __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
@@ -145,6 +146,12 @@ struct Plan {
 template <typename T>
 bool pass1(const Plan<T> &pl, const T *A, const T *p, uint64_t n, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch)
 {
+    if (g_shard_P > 0) {
+        const uint64_t R0 = g_shard_q * (n / g_shard_P), rp = (n / g_shard_P + 63) / 64 * 64;
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, rp, n, R0, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, rp, n, R0, (const lam::CgScalars *)nullptr);
+        return true;
+    }
     if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, false>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
     else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, false>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
     else return false;
@@ -156,6 +163,12 @@ bool pass2(const Plan<T> &pl, const T *p, T *y, double *partial, uint64_t n, uin
     const unsigned grid = (unsigned)((n + lam::kSymvReduceRows - 1) / lam::kSymvReduceRows);
     lam::PtrList none;
     none.n = 0;
+    if (g_shard_P > 0) {
+        const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc, rp = (nloc + 63) / 64 * 64;
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, (const lam::CgScalars *)nullptr);
+        return true;
+    }
     if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, (const lam::CgScalars *)nullptr);
     else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, (const lam::CgScalars *)nullptr);
     else return false;
@@ -200,6 +213,35 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
         // row boundaries of the schedule classes, aligned so that every class starts on a multiple of the largest height
         std::vector<uint64_t> upto;
         for (auto &c : pl.sched) upto.push_back(c.second >= 1.0 ? n : (uint64_t)(c.second * (double)n) / kRowsMax * kRowsMax);
+        if (g_shard_P > 0) {
+            // one row shard, the library's cyclic half windows (lam_launch.h, build_symv_tasks); the schedule's fractions are of the shard's rows
+            const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc, H = (n - 1) / 2;
+            std::vector<uint64_t> up;
+            for (auto &c : pl.sched) up.push_back(c.second >= 1.0 ? nloc : (uint64_t)(c.second * (double)nloc) / kRowsMax * kRowsMax);
+            auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };
+            std::vector<std::vector<Task>> per_strip(pl.nstrips);
+            for (uint64_t r = 0; r < nloc;) {
+                size_t cls = 0;
+                while (cls + 1 < pl.sched.size() && r >= up[cls]) cls++;
+                const uint64_t hgt = std::min<uint64_t>(nloc - r, (uint64_t)pl.sched[cls].first), ga = R0 + r, gb = ga + hgt;
+                for (uint32_t st = 0; st < pl.nstrips; st++) {
+                    const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;
+                    if (!(meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2))) continue;
+                    bool in = false;
+                    for (uint64_t k2 = 0; k2 < 2; k2++) {
+                        const uint64_t u0 = c0 + k2 * n, u1 = c0 + SS - 1 + k2 * n;
+                        in = in || (u0 >= gb && u1 - ga <= H);
+                    }
+                    const bool interior = c0 + SS <= ncols_vec && hgt % 8 == 0 && c0 + SS <= n && in;
+                    per_strip[st].push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), st, 0});
+                }
+                r += hgt;
+            }
+            for (uint32_t st = 0; st < pl.nstrips; st++) {
+                slot_base[st + 1] = slot_base[st] + (uint32_t)per_strip[st].size();
+                for (size_t k2 = 0; k2 < per_strip[st].size(); k2++) { per_strip[st][k2].slot = slot_base[st] + (uint32_t)k2; tasks.push_back(per_strip[st][k2]); }
+            }
+        } else
         for (uint32_t s = 0; s < pl.nstrips; s++) {
             const uint64_t rows = std::min<uint64_t>(n, (uint64_t)s * SS + SS);
             uint32_t k = 0;
@@ -221,14 +263,14 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
         CHK(hipMalloc(&pl.dt, tasks.size() * sizeof(Task))); CHK(hipMalloc(&pl.dsb, slot_base.size() * 4));
         CHK(hipMemcpy(pl.dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
         CHK(hipMemcpy(pl.dsb, slot_base.data(), slot_base.size() * 4, hipMemcpyHostToDevice));
-        CHK(hipMemset(pl.colpart, 0xff, (size_t)pl.ntasks * SS * sizeof(T)));     // NaNs: every slot the reduce reads must have been written
+        CHK(hipMemset(pl.colpart, g_shard_P > 0 ? 0 : 0xff, (size_t)pl.ntasks * SS * sizeof(T)));     // NaNs: every slot the reduce reads must have been written
         CHK(hipMemset(pl.rowpart, 0, (size_t)pl.nstrips * row_pitch * sizeof(T)));       // (strip, row) pairs no task covers stay zero
         if (!pass1(pl, A, p, n, lda, ncols_vec, row_pitch) || !pass2(pl, p, y, partial, n, row_pitch)) { printf("shape of %s not compiled in\n", spec.c_str()); return 1; }
         CHK(hipDeviceSynchronize());
         CHK(hipMemcpy(h.data(), y, n * sizeof(T), hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < n; i++) {
             if (!(h[i] == h[i])) pl.err = 1e300;
-            pl.err = std::max(pl.err, std::fabs((double)h[i] - (double)hr[i]) / maxref);
+            if (g_shard_P == 0) pl.err = std::max(pl.err, std::fabs((double)h[i] - (double)hr[i]) / maxref);   // a shard's contribution is not the product
         }
         plans.push_back(pl);
     }
@@ -253,7 +295,9 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
         }
     }
     auto stat = [](std::vector<double> v, double *mn, double *med) { std::sort(v.begin(), v.end()); *mn = v[0]; *med = v[v.size() / 2]; };
-    const double gb_full = (double)sizeof(T) * n * n / 1e9, gb_tri = gb_full / 2 + (double)sizeof(T) * n / 2 / 1e9;
+    const double gb_full = (double)sizeof(T) * n * n / 1e9, gb_tri = (gb_full / 2 + (double)sizeof(T) * n / 2 / 1e9) / (g_shard_P > 0 ? (double)g_shard_P : 1.0);
+    if (g_shard_P > 0) printf("shard %llu of %llu: rows [%llu, %llu), cyclic half windows; its bytes = %.3f GB\n", (unsigned long long)g_shard_q, (unsigned long long)g_shard_P,
+                              (unsigned long long)(g_shard_q * (n / g_shard_P)), (unsigned long long)((g_shard_q + 1) * (n / g_shard_P)), gb_tri);
     double mn, med;
     stat(tf, &mn, &med);
     printf("N=%llu %s lda=%llu, %d interleaved rounds of 5 launches; triangle = %.2f GB\n", (unsigned long long)n, sizeof(T) == 8 ? "fp64" : "fp32",
@@ -278,6 +322,7 @@ int main(int argc, char **argv)
     const uint64_t n = strtoull(argv[1], nullptr, 10);
     const bool f32 = !strcmp(argv[2], "f32");
     if (getenv("SYMV2_STREAM")) CHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (const char *sh = getenv("SYMV2_SHARD")) { unsigned long long q = 0, P = 0; if (sscanf(sh, "%llu/%llu", &q, &P) == 2 && P > 0 && q < P && n % P == 0) { g_shard_q = q; g_shard_P = P; } }
     const int rounds = atoi(argv[3]);
     std::vector<std::string> specs;
     for (int i = 4; i < argc; i++) specs.push_back(argv[i]);
