@@ -6,7 +6,7 @@ tests and bench.py; the host-side drop-in for the reference's C++ classes lives 
 gfx950 GPU, every compute call raises.
 """
 from ._capi import (  # noqa: F401
-    LamHipError, Stats, Solver, build, lib, lib_path, device_count, get_unique_id, partition, rccl_version,
+    LamHipError, Stats, Solver, build, lib, lib_path, device_count, get_unique_id, partition, rccl_version, symv_plan_check,
     F64, F32, BF16, TUNING_LIB,
 )
 from ._rendezvous import Rendezvous, launched_with_ranks  # noqa: F401,E402

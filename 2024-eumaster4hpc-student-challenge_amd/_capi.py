@@ -113,6 +113,7 @@ def lib():
             "lam_hip_gemv": ([vp, vp, vp], i32),
             "lam_hip_gemv_only": ([vp, i32, C.POINTER(C.c_double)], i32),
             "lam_hip_check_symmetry": ([vp, C.POINTER(C.c_double)], i32),
+            "lam_hip_debug_symv_plan": ([u64, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)], i32),
             "lam_hip_dot": ([vp, vp, vp, u64, C.POINTER(C.c_double)], i32),
             "lam_hip_axpby": ([vp, C.c_double, vp, C.c_double, vp, u64], i32),
             "lam_hip_all_ok": ([vp, i32, C.POINTER(i32)], i32),
@@ -155,6 +156,15 @@ def rccl_version():
     if rc != 0:
         raise LamHipError(rc, (lib().lam_hip_last_error(None) or b"").decode())
     return v.value
+
+
+def symv_plan_check(n, shards, dtype=0):
+    """Host-only check of the symmetric product's task plan (lam_hip_debug_symv_plan): (bad_pairs, bad_interior, tasks)."""
+    bp, bi, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = lib().lam_hip_debug_symv_plan(n, shards, dtype, C.byref(bp), C.byref(bi), C.byref(nt))
+    if rc != 0:
+        raise LamHipError(rc, "lam_hip_debug_symv_plan")
+    return bp.value, bi.value, nt.value
 
 
 def partition(n, num_shards, shard):

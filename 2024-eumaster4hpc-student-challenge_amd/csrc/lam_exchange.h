@@ -738,10 +738,16 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
                 s.split_slot[slot] = false;
                 s.timed_slot[slot] = timed;
                 if (timed) RECORD(c, s.ev_g0[slot], s.stream);
-                LAMCHK(I::launch_symv(c, s, (const TV *)s.p, nullptr, s.part_gemv, s.sc, &recs));
-                hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv,
-                                   I::symv_reduce_grid(c->n), tails, 0, (const CgScalars *)s.sc);
-                LAUNCHED(c);
+                Finalize fs = no_finalize(c);
+                fs.active = c->opt_finalize ? 1 : 0;
+                fs.slot = 0;
+                fs.dst = tails;
+                LAMCHK(I::launch_symv(c, s, (const TV *)s.p, nullptr, s.part_gemv, s.sc, &recs, &fs));
+                if (!c->opt_finalize) {
+                    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv,
+                                       I::symv_reduce_grid(c->n), tails, 0, (const CgScalars *)s.sc);
+                    LAUNCHED(c);
+                }
                 if (timed) RECORD(c, s.ev_g1[slot], s.stream);
                 if (!(c->opt_join && &s == &c->sh[0])) RECORD(c, s.ev_a, s.stream);
                 continue;
@@ -855,15 +861,21 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         s.timed_slot[slot] = timed;
         if (timed) RECORD(c, s.ev_g0[slot], s.stream);
         if (sym) {
-            // the symmetric product's two passes leave this rank's full-length contribution in its record, a 1-block launch its p.Ap part
+            // the symmetric product's two passes leave this rank's full-length contribution and its p.Ap part in its record
             PtrList recs, tails;
             recs.n = tails.n = 1;
             recs.p[0] = rec;
             tails.p[0] = rec + stride - 8;
-            LAMCHK(I::launch_symv(c, s, (const TV *)s.p, nullptr, s.part_gemv, s.sc, &recs));
-            hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv, I::symv_reduce_grid(c->n),
-                               tails, 0, (const CgScalars *)s.sc);
-            LAUNCHED(c);
+            Finalize fs = no_finalize(c);
+            fs.active = c->opt_finalize ? 1 : 0;
+            fs.slot = 0;
+            fs.dst = tails;
+            LAMCHK(I::launch_symv(c, s, (const TV *)s.p, nullptr, s.part_gemv, s.sc, &recs, &fs));
+            if (!c->opt_finalize) {
+                hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(kBlock), 0, s.stream, (const double *)s.part_gemv,
+                                   I::symv_reduce_grid(c->n), tails, 0, (const CgScalars *)s.sc);
+                LAUNCHED(c);
+            }
         } else {
         LAMCHK(I::launch_gemv(c, s, (const TV *)s.p, (TV *)rec, s.part_gemv, s.sc, 0, 0, 0, &f));
         }

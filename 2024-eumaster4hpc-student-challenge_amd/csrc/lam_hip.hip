@@ -955,6 +955,51 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
     });
 }
 
+int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pairs, uint64_t *bad_interior, uint64_t *ntasks)
+{
+    if (n == 0 || shards < 1 || shards > kMaxShards || (uint64_t)shards > n || !bad_pairs || !bad_interior || !ntasks ||
+        (dtype != LAM_HIP_F64 && dtype != LAM_HIP_F32))
+        return LAM_HIP_EINVAL;
+    const uint64_t vec = dtype == LAM_HIP_F64 ? 2 : 4, SS = (uint64_t)kBlock * vec, ncv = (n + vec - 1) / vec * vec;   // NV = 1, as launched
+    const bool cyc = shards > 1;
+    std::vector<uint8_t> count(n * n, 0);                 // count[i * n + j]: how often y_i += A_ij p_j is produced
+    auto bump = [&](uint64_t i, uint64_t j) { uint8_t &c = count[i * n + j]; if (c < 255) c++; };
+    *bad_interior = 0;
+    *ntasks = 0;
+    for (int q = 0; q < shards; q++) {
+        uint64_t R0 = 0, nloc = 0;
+        partition(n, shards, q, &R0, &nloc);
+        std::vector<SymvTask> tasks;
+        std::vector<uint32_t> slot_base;
+        symv_plan(n, ncv, SS, R0, nloc, cyc, &tasks, &slot_base);
+        *ntasks += tasks.size();
+        for (const SymvTask &t : tasks) {
+            const bool interior = (t.nrows & kSymvInterior) != 0;
+            const uint64_t h = t.nrows & ~kSymvInterior, c0 = (uint64_t)t.strip * SS;
+            if (t.row0 + h > nloc) return LAM_HIP_EINVAL;
+            for (uint64_t r = 0; r < h; r++) {
+                const uint64_t grow = R0 + t.row0 + r;
+                for (uint64_t col = c0; col < c0 + SS; col++) {
+                    if (col >= ncv) { if (interior) ++*bad_interior; continue; }      // the kernel's `live` test (interior: no test)
+                    bool rs, cs;
+                    if (cyc) symv_use<true>(col, grow, n, &rs, &cs); else symv_use<false>(col, grow, n, &rs, &cs);
+                    if (interior) {                      // processed without any test: must be what the tests would have said
+                        if (!(rs && cs) || col >= n) ++*bad_interior;
+                        rs = cs = true;
+                    }
+                    if (col >= n) continue;              // padding column: the matrix holds zeros there, p likewise
+                    if (rs) bump(grow, col);             // y_grow += A[grow][col] p[col]
+                    if (cs) bump(col, grow);             // y_col  += A[grow][col] p[grow]  (A[col][grow] by symmetry)
+                }
+            }
+        }
+    }
+    uint64_t bad = 0;
+    for (uint8_t c : count) bad += c != 1;
+    *bad_pairs = bad;
+    return 0;
+}
+
 int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t n, double *result)
 {
     if (!c || !x_host || !y_host || !result) return LAM_HIP_EINVAL;

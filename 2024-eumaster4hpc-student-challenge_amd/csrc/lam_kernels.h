@@ -1111,7 +1111,7 @@ __device__ __forceinline__ T wave_sum8(const T (&v)[8])
 // d = N/2 for the rows of the upper half only: every pair {i, j} is covered once, every row does the same work, contiguous row
 // shards stay balanced.
 template <bool CYC>
-__device__ __forceinline__ void symv_use(uint64_t col, uint64_t grow, uint64_t n, bool *row_side, bool *col_side)
+__host__ __device__ __forceinline__ void symv_use(uint64_t col, uint64_t grow, uint64_t n, bool *row_side, bool *col_side)
 {
     if (!CYC) { *row_side = col >= grow; *col_side = col > grow; return; }
     const uint64_t d = col >= grow ? col - grow : col + n - grow;
@@ -1270,17 +1270,22 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
 // covers keeps the zero it was allocated with) for the rows this shard owns, [row_off, row_off + nloc); column side: the
 // colpart slots of i's strip.  One shard: y is the product, `partial` its p.y per workgroup.  Several shards (dst.n > 0): the
 // entry is this shard's CONTRIBUTION to y[i], stored into its record in every shard's gather buffer; the consumer adds the
-// shards' records in shard order.
+// shards' records in shard order; the launch carries one extra workgroup (fin.active) that sums the workgroups' parts of p.Ap
+// in the fixed order of block_sum_array and writes the total behind the record (see Finalize).
 template <typename T, int NV>
 __global__ void __launch_bounds__(kBlock)
 symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const uint32_t *__restrict__ slot_base,
                    const T *__restrict__ p, T *__restrict__ y, double *__restrict__ partial, uint64_t n, uint64_t row_pitch,
-                   uint32_t nstrips, uint64_t row_off, uint64_t nloc, PtrList dst, const CgScalars *sc)
+                   uint32_t nstrips, uint64_t row_off, uint64_t nloc, PtrList dst, Finalize fin, const CgScalars *sc)
 {
     constexpr int SS = NV * kBlock * MatVec<T>::N, RB = kSymvReduceRows, G = kBlock / RB;
     __shared__ T s[G][RB];
     __shared__ double s_dot[RB];
     if (sc != nullptr && sc->stop) return;
+    if (is_reducer_block(fin)) {                        // several shards: the shard's part of p.Ap as ONE number, inside this launch
+        reduce_partials(partial, (int)compute_blocks(fin), fin, s_dot);
+        return;
+    }
     const int l = threadIdx.x % RB, g = threadIdx.x / RB;
     const uint64_t i = (uint64_t)blockIdx.x * RB + l;
     T acc = (T)0;
@@ -1322,7 +1327,7 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
         double d = 0.0;
 #pragma unroll
         for (int k = 0; k < RB; k++) d += s_dot[k];
-        partial[blockIdx.x] = d;
+        publish_partial(d, partial, fin);               // plain store, or the self-flagging slot the reducer workgroup waits for
     }
 }
 

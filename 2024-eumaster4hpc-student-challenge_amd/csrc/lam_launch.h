@@ -5,6 +5,62 @@
 namespace {
 
 // ---- typed implementation ----------------------------------------------------------------------
+// The symmetric product's task list for one shard (rows [R0, R0 + nloc) of an n x n matrix, strips of SS columns, ncv = columns a
+// row holds in whole vectors): pure host arithmetic, shared by the launcher below and by lam_hip_debug_symv_plan (a CPU test
+// counts that every directed pair (i <- j) is produced exactly once and that no task flagged interior has an unused element).
+void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc, bool cyc, std::vector<SymvTask> *out_tasks,
+               std::vector<uint32_t> *out_slot_base)
+{
+    const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
+    const uint64_t H = (n - 1) / 2;
+    uint64_t tall = cyc ? 8 : 32, split;
+    if (!cyc) {
+        while (tall < (uint64_t)kSymvRowsMax && tall * 64 <= n) tall *= 2;
+        split = (uint64_t)(0.65 * (double)n) / kSymvRowsMax * kSymvRowsMax;
+    } else {
+        const uint64_t strips_per_run = n / 2 / SS + 2;
+        while (tall < (uint64_t)kSymvRowsMax && nloc * strips_per_run / (2 * tall) >= 6000) tall *= 2;
+        split = (uint64_t)(0.85 * (double)nloc) / kSymvRowsMax * kSymvRowsMax;
+    }
+    const uint64_t small = tall / 8 < 8 ? 8 : tall / 8;
+    auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };   // closed intervals
+    std::vector<SymvTask> &tasks = *out_tasks;
+    std::vector<std::vector<SymvTask>> per_strip(nstrips);
+    for (uint64_t r = 0; r < nloc;) {
+        const uint64_t h = std::min<uint64_t>(nloc - r, r < split ? tall : small);
+        const uint64_t ga = R0 + r, gb = ga + h;                   // global rows [ga, gb)
+        for (uint32_t st = 0; st < nstrips; st++) {
+            const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;     // real columns [c0, c1]
+            bool needed, interior = c0 + SS <= n && h % 8 == 0;       // the whole strip inside the matrix: no padding column
+            if (!cyc) {
+                needed = c1 >= ga;                                 // some column at or right of the first row's diagonal
+                interior = interior && c0 >= gb;                   // every column right of every row
+            } else {
+                // the union of the rows' windows (diagonal and antipode included) is the cyclic interval [ga, gb - 1 + n / 2]
+                needed = meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2);
+                bool in = false;
+                for (uint64_t k = 0; k < 2; k++) {                 // the strip as it lies behind the rows, unwrapped
+                    const uint64_t u0 = c0 + k * n, u1 = c0 + SS - 1 + k * n;
+                    in = in || (u0 >= gb && u1 - ga <= H);         // 1 <= d <= (n - 1) / 2 for every row and column
+                }
+                interior = interior && in;
+            }
+            if (!needed) continue;
+            per_strip[st].push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u), st, 0});
+        }
+        r += h;
+    }
+    out_slot_base->assign(nstrips + 1, 0);
+    for (uint32_t st = 0; st < nstrips; st++) {
+        (*out_slot_base)[st + 1] = (*out_slot_base)[st] + (uint32_t)per_strip[st].size();
+        for (size_t k = 0; k < per_strip[st].size(); k++) {
+            per_strip[st][k].slot = (*out_slot_base)[st] + (uint32_t)k;
+            tasks.push_back(per_strip[st][k]);
+        }
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const SymvTask &a, const SymvTask &b) { return a.row0 < b.row0; });
+}
+
 template <typename TA, typename TV>
 struct Impl {
     static constexpr int VEC = MatVec<TA>::N;
@@ -120,55 +176,12 @@ struct Impl {
     template <int NV>
     static int build_symv_tasks(lam_hip_ctx *c, ShardBase &s, bool cyc)
     {
-        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec(), nloc = s.nrows, R0 = s.row0;
+        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec(), nloc = s.nrows;
         const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
-        const uint64_t row_pitch = (nloc + 63) / 64 * 64, H = (n - 1) / 2;
-        uint64_t tall = cyc ? 8 : 32, split;
-        if (!cyc) {
-            while (tall < (uint64_t)kSymvRowsMax && tall * 64 <= n) tall *= 2;
-            split = (uint64_t)(0.65 * (double)n) / kSymvRowsMax * kSymvRowsMax;
-        } else {
-            const uint64_t strips_per_run = n / 2 / SS + 2;
-            while (tall < (uint64_t)kSymvRowsMax && nloc * strips_per_run / (2 * tall) >= 6000) tall *= 2;
-            split = (uint64_t)(0.85 * (double)nloc) / kSymvRowsMax * kSymvRowsMax;
-        }
-        const uint64_t small = tall / 8 < 8 ? 8 : tall / 8;
-        auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };   // closed intervals
+        const uint64_t row_pitch = (nloc + 63) / 64 * 64;
         std::vector<SymvTask> tasks;
-        std::vector<std::vector<SymvTask>> per_strip(nstrips);
-        for (uint64_t r = 0; r < nloc;) {
-            const uint64_t h = std::min<uint64_t>(nloc - r, r < split ? tall : small);
-            const uint64_t ga = R0 + r, gb = ga + h;                   // global rows [ga, gb)
-            for (uint32_t st = 0; st < nstrips; st++) {
-                const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;     // real columns [c0, c1]
-                bool needed, interior = c0 + SS <= ncv && h % 8 == 0;
-                if (!cyc) {
-                    needed = c1 >= ga;                                 // some column at or right of the first row's diagonal
-                    interior = interior && c0 >= gb;                   // every column right of every row
-                } else {
-                    // the union of the rows' windows (diagonal and antipode included) is the cyclic interval [ga, gb - 1 + n / 2]
-                    needed = meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2);
-                    bool in = false;
-                    for (uint64_t k = 0; k < 2; k++) {                 // the strip as it lies behind the rows, unwrapped
-                        const uint64_t u0 = c0 + k * n, u1 = c0 + SS - 1 + k * n;
-                        in = in || (u0 >= gb && u1 - ga <= H);         // 1 <= d <= (n - 1) / 2 for every row and column
-                    }
-                    interior = interior && c0 + SS <= n && in;
-                }
-                if (!needed) continue;
-                per_strip[st].push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u), st, 0});
-            }
-            r += h;
-        }
-        std::vector<uint32_t> slot_base(nstrips + 1, 0);
-        for (uint32_t st = 0; st < nstrips; st++) {
-            slot_base[st + 1] = slot_base[st] + (uint32_t)per_strip[st].size();
-            for (size_t k = 0; k < per_strip[st].size(); k++) {
-                per_strip[st][k].slot = slot_base[st] + (uint32_t)k;
-                tasks.push_back(per_strip[st][k]);
-            }
-        }
-        std::stable_sort(tasks.begin(), tasks.end(), [](const SymvTask &a, const SymvTask &b) { return a.row0 < b.row0; });
+        std::vector<uint32_t> slot_base;
+        symv_plan(n, ncv, SS, s.row0, nloc, cyc, &tasks, &slot_base);
         if (tasks.empty()) return fail(c, LAM_HIP_EINVAL, "symmetric product: no tasks");
         // all four or none: a later failure must not leave the earlier buffers behind
         DevBuf t, rp, cp, sb;
@@ -190,7 +203,8 @@ struct Impl {
     // the two passes.  dst.n == 0: one shard, y = A p and `partial` = the p.y partials (symv_reduce_grid(n) of them).  dst.n > 0:
     // several shards, the shard's full-length contribution goes into dst.p[] (its record in every shard's gather buffer).
     template <int NV>
-    static int launch_symv_nv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList &dst)
+    static int launch_symv_nv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList &dst,
+                              const Finalize &fin)
     {
         const bool cyc = dst.n > 0;
         const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec();
@@ -204,9 +218,9 @@ struct Impl {
             hipLaunchKernelGGL((symv_task_kernel<TA, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
                                (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, n, s.row0, sc);
         HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n)), dim3(kBlock), 0, s.stream, (const TA *)s.symv_rowpart,
-                           (const TA *)s.symv_colpart, (const uint32_t *)s.symv_slot_base, (const TA *)p, (TA *)y, partial, n, row_pitch,
-                           nstrips, s.row0, s.nrows, dst, sc);
+        hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n) + (fin.active ? 1 : 0)), dim3(kBlock), 0, s.stream,
+                           (const TA *)s.symv_rowpart, (const TA *)s.symv_colpart, (const uint32_t *)s.symv_slot_base, (const TA *)p, (TA *)y,
+                           partial, n, row_pitch, nstrips, s.row0, s.nrows, dst, fin, sc);
         HIPCHK(c, hipGetLastError());
         c->n_launch += 2;
         return 0;
@@ -215,13 +229,18 @@ struct Impl {
     // vectors per lane and row: one everywhere -- with the pipelined interior loop one 4-KiB strip per workgroup runs level with
     // two at N = 65536 (fp64) / 131072 (fp32) and 2-5 % ahead at N <= 40000 (profiles/r04_symv2_probe.txt); two stays compiled
     static int symv_nv(const lam_hip_ctx *) { return 1; }
-    static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList *dst = nullptr)
+    // `fin` (several shards): where the reducer workgroup of the second pass writes the shard's part of p.Ap
+    static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList *dst = nullptr,
+                           const Finalize *fin = nullptr)
     {
         if constexpr (std::is_same<TA, TV>::value) {
             PtrList none;
             none.n = 0;
             const PtrList &d = dst ? *dst : none;
-            return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc, d) : launch_symv_nv<1>(c, s, p, y, partial, sc, d);
+            Finalize off;
+            off.active = 0; off.mail = 0; off.seq = 0; off.dst.n = 0; off.slot = 0; off.host_err = c->direct_err;
+            const Finalize &f = fin ? *fin : off;
+            return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc, d, f) : launch_symv_nv<1>(c, s, p, y, partial, sc, d, f);
         } else {
             return fail(c, LAM_HIP_EINVAL, "the symmetric product needs matrix and vector of one type");
         }

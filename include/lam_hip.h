@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 /* 2 (round 4): lam_hip_build_id (added in round 3 without a bump) and lam_hip_generate_spectrum_spd; nothing removed or changed */
-#define LAM_HIP_ABI_VERSION 2
+#define LAM_HIP_ABI_VERSION 3
 
 /* storage / arithmetic type of the matrix and vectors */
 #define LAM_HIP_F64 0  /* double everywhere (the reference drivers hard-code <double>) */
@@ -198,6 +198,14 @@ int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double bet
 /* max |A[i][j] - A[j][i]| of the matrix held by a single-shard context (fp64/fp32 storage): lets a caller
  * verify the precondition of option "symmetric".  No reference counterpart. */
 int lam_hip_check_symmetry(lam_hip_ctx *ctx, double *max_abs_asymmetry);
+
+/* Host-only check of the symmetric product's PLAN (no device needed, no context): builds the task lists of all `shards` row shards
+ * of an n x n problem of `dtype` exactly as the launcher does, walks every element of every task through the kernel's own use rule,
+ * and reports how many directed products (y_i += A_ij p_j, i and j in [0, n)) are produced not exactly once (*bad_pairs, must be
+ * 0) and how many elements of tasks flagged "interior" -- which the kernel processes without any test -- are not used by both
+ * sides or lie outside the matrix (*bad_interior, must be 0); *tasks = number of tasks.  shards == 1: the upper triangle; more:
+ * cyclic half windows.  O(n^2) time, n^2 bytes of memory: for tests (n <= ~8192).  No reference counterpart. */
+int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pairs, uint64_t *bad_interior, uint64_t *tasks);
 
 /* Agreement across ranks (collective in rank mode, identity otherwise): *global_ok = 1 iff every rank passed
  * local_ok != 0.  Lets a step that can fail on ONE rank (reading its row block from a file) fail on ALL of

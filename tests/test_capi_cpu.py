@@ -6,6 +6,8 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -27,7 +29,7 @@ def test_library_exports_every_declared_symbol(lam):
 def test_binding_covers_header(lam):
     L = lam.lib()
     assert set(_declared_symbols()) == set(L._lam_symbols)
-    assert L.lam_hip_abi_version() == 2
+    assert L.lam_hip_abi_version() == 3
 
 
 def test_build_id_covers_every_source_of_the_translation_unit(lam):
@@ -143,3 +145,23 @@ def test_stale_library_is_refused(lam):
             "except ImportError as e:\n    print('REFUSED', e)\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "REFUSED" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_symmetric_product_plan_covers_every_pair_once(lam, dtype):
+    """Host logic of option "symmetric" without a GPU: lam_hip_debug_symv_plan builds the task lists of every shard exactly as the
+    launcher does and walks each element through the kernel's own use rule (symv_use, compiled for the host as well).  Every
+    directed product y_i += A_ij p_j must come out exactly once -- one shard: the upper triangle; several: cyclic half windows,
+    antipodes of even N to the upper half's rows -- and a task flagged interior (processed without any test) may hold no element
+    that the rule would have left out.  Odd and even N, N below / at / above a strip (512 fp64, 1024 fp32 columns), N not a
+    multiple of the vector, shards that do not divide N (the plan itself does not need that; the exchange does)."""
+    sizes = [1, 2, 3, 7, 64, 77, 511, 512, 513, 1000, 1023, 1024, 1025, 1536, 2050, 3000, 4097]
+    for n in sizes:
+        for shards in (1, 2, 3, 4, 5, 8):
+            if shards > n:
+                continue
+            bad_pairs, bad_interior, tasks = lam.symv_plan_check(n, shards, dtype)
+            assert (bad_pairs, bad_interior) == (0, 0) and tasks > 0, (n, shards, dtype, bad_pairs, bad_interior, tasks)
+    # a larger one with many interior tasks in both forms
+    for n, shards in ((6144, 1), (6144, 8), (5000, 4)):
+        assert lam.symv_plan_check(n, shards, dtype)[:2] == (0, 0)

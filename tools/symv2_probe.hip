@@ -163,14 +163,16 @@ bool pass2(const Plan<T> &pl, const T *p, T *y, double *partial, uint64_t n, uin
     const unsigned grid = (unsigned)((n + lam::kSymvReduceRows - 1) / lam::kSymvReduceRows);
     lam::PtrList none;
     none.n = 0;
+    lam::Finalize nofin;
+    nofin.active = 0; nofin.mail = 0; nofin.seq = 0; nofin.dst.n = 0; nofin.slot = 0; nofin.host_err = nullptr;
     if (g_shard_P > 0) {
         const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc, rp = (nloc + 63) / 64 * 64;
-        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, (const lam::CgScalars *)nullptr);
-        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, (const lam::CgScalars *)nullptr);
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
         return true;
     }
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, (const lam::CgScalars *)nullptr);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -232,7 +234,7 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
                         const uint64_t u0 = c0 + k2 * n, u1 = c0 + SS - 1 + k2 * n;
                         in = in || (u0 >= gb && u1 - ga <= H);
                     }
-                    const bool interior = c0 + SS <= ncols_vec && hgt % 8 == 0 && c0 + SS <= n && in;
+                    const bool interior = c0 + SS <= n && hgt % 8 == 0 && in;
                     per_strip[st].push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), st, 0});
                 }
                 r += hgt;
@@ -249,7 +251,7 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
                 size_t cls = 0;
                 while (cls + 1 < pl.sched.size() && r >= upto[cls]) cls++;
                 const uint64_t hgt = std::min<uint64_t>(rows - r, (uint64_t)pl.sched[cls].first);
-                const bool interior = (uint64_t)s * SS + SS <= ncols_vec && hgt % 8 == 0 && (uint64_t)s * SS >= r + hgt;   // as the library
+                const bool interior = (uint64_t)s * SS + SS <= n && hgt % 8 == 0 && (uint64_t)s * SS >= r + hgt;   // as the library
                 tasks.push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), s, slot_base[s] + k});
                 k++;
                 r += hgt;
