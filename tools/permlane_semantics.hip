@@ -1,3 +1,5 @@
+// permlane_semantics -- what v_permlane32_swap / v_permlane16_swap and the DPP controls used by wave_sum8 (lam_kernels.h) do on gfx950, printed
+// lane by lane: the transposed butterfly was written against this output.  hipcc --offload-arch=gfx950 -O2 tools/permlane_semantics.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned *o) {

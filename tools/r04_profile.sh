@@ -1,3 +1,4 @@
+# Round-4 profile run: the bench command un-profiled and under rocprofv3 --kernel-trace --stats, general GEMV and option symmetric (one gpurun call).
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/r04d_prof_stats gpurun_out/r04d_prof_stats_sym
