@@ -119,3 +119,104 @@ def test_partition_function_matches_reference_rule(lam, oracle):
         assert sum(nr for _, nr in got) == n and got[0][0] == 0
         assert all(got[q][0] + got[q][1] == got[q + 1][0] for q in range(P - 1))
         assert got[-1][1] == n // P + n % P          # remainder on the LAST shard
+
+
+# ------------------------------------------------------------------------------------------------
+# option "symmetric" on row shards: the exchange protocol (gather of full-length contributions), world size 2 and 3
+# ------------------------------------------------------------------------------------------------
+def _window_masks(n, rows):
+    """The kernel's use rule (csrc/lam_kernels.h, symv_use<CYC = true>) restated for whole rows: row r uses column c on its row
+    side if d = (c - r) mod n is 0 or lies in its window, on its column side if it lies in the window; the window is
+    1 <= d <= (n - 1) // 2 plus, for even n, the antipode d = n / 2 for the rows of the upper half."""
+    r = np.asarray(rows)[:, None]
+    d = (np.arange(n)[None, :] - r) % n
+    win = ((d >= 1) & (d <= (n - 1) // 2)) | ((n % 2 == 0) & (d == n // 2) & (r < n // 2))
+    return (d == 0) | win, win
+
+
+def _sym_worker(rank, world, port, n, iters, outdir, parts):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    M = rng.uniform(-1, 1, (n, n))
+    A = 0.5 * (M + M.T) + n * np.eye(n)                 # the same SPD matrix on every rank (seeded); a rank USES its rows only
+    b = rng.uniform(-1, 1, n)
+    row0, nrows = parts[rank]
+    A_loc = A[row0:row0 + nrows]
+    row_side, col_side = _window_masks(n, range(row0, row0 + nrows))
+
+    def product(p):
+        """This rank's full-length contribution to A p and its part of p.Ap; then the iteration's ONE exchange: all ranks gather
+        every rank's record and add them in rank order (lam_exchange.h, symmetric product on several shards)."""
+        contrib = np.zeros(n)
+        contrib[row0:row0 + nrows] = (A_loc * row_side) @ p                         # y_r += A_rc p_c over the row's window (+ diagonal)
+        contrib += (A_loc * col_side).T @ p[row0:row0 + nrows]                       # y_c += A_rc p_r for the same elements
+        rec = torch.from_numpy(np.concatenate([contrib, [float(p @ contrib)]]))
+        out = [torch.empty(n + 1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, rec)
+        Ap, pAp = out[0][:n].numpy().copy(), float(out[0][n])
+        for q in range(1, world):
+            Ap += out[q][:n].numpy()
+            pAp += float(out[q][n])
+        return Ap, pAp
+
+    # gather-Ap iteration: full-length r and p on every rank, x on the own slice; r.r needs no exchange
+    x = np.zeros(nrows); r = b.copy(); p = b.copy(); rr = float(r @ r)
+    Ap0 = None
+    for k in range(iters):
+        Ap, pAp = product(p)
+        if k == 0:
+            Ap0 = Ap.copy()
+        alpha = rr / pAp
+        x += alpha * p[row0:row0 + nrows]
+        r -= alpha * Ap
+        rr_new = float(r @ r)
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+    xs = [None] * world
+    dist.all_gather_object(xs, (x, r, Ap0))
+    if rank == 0:
+        assert all(np.array_equal(xs[0][1], t[1]) and np.array_equal(xs[0][2], t[2]) for t in xs)     # identical r, A p on every rank
+        np.save(os.path.join(outdir, "x.npy"), np.concatenate([t[0] for t in xs]))
+        np.save(os.path.join(outdir, "Ap0.npy"), Ap0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (3, 99), (2, 51)])
+def test_symmetric_row_shard_protocol(world, n, tmp_path):
+    """Every rank contributes, from ITS rows only, the products of each row's cyclic half window and their mirror images; the
+    gathered records added in rank order are A p -- every pair once, odd and even n, uneven last block --, identical on all
+    ranks, and the gather-Ap recurrence on top of it follows plain CG."""
+    import importlib
+    import multiprocessing
+    lam = importlib.import_module(PKG_NAME)
+    parts = [lam.partition(n, world, q) for q in range(world)]
+    assert lam.symv_plan_check(n, world)[:2] == (0, 0)                 # the product's own plan for this split covers every pair once
+    ctx = multiprocessing.get_context("spawn")
+    port = 29700 + world + (os.getpid() % 200)
+    iters = 12
+    procs = [ctx.Process(target=_sym_worker, args=(r, world, port, n, iters, str(tmp_path), parts)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, f"worker exit code {pr.exitcode}"
+    rng = np.random.default_rng(11)
+    M = rng.uniform(-1, 1, (n, n))
+    A = 0.5 * (M + M.T) + n * np.eye(n)
+    b = rng.uniform(-1, 1, n)
+    np.testing.assert_allclose(np.load(tmp_path / "Ap0.npy"), A @ b, rtol=1e-13, atol=1e-13)
+    x = np.zeros(n); r = b.copy(); p = b.copy(); rr = r @ r          # plain CG, same number of iterations
+    for _ in range(iters):
+        Ap = A @ p
+        alpha = rr / (p @ Ap)
+        x += alpha * p; r -= alpha * Ap
+        rr_new = r @ r
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+    np.testing.assert_allclose(np.load(tmp_path / "x.npy"), x, rtol=1e-10, atol=1e-14)
