@@ -39,7 +39,8 @@ struct ShardBase {
     size_t ap_gather_bytes = 0;
     void *symv_rowpart = nullptr, *symv_colpart = nullptr;   // symmetric product (option "symmetric")
     SymvTask *symv_tasks = nullptr;
-    uint32_t *symv_slot_base = nullptr;   // [strips + 1]: first colpart slot of every strip
+    uint32_t *symv_index = nullptr;       // what the second pass needs to find the partials (lam_kernels.h, SymvIndex)
+    SymvIndex symv_ix = {};
     int symv_ntasks = 0;
     void *symv_gather = nullptr;          // several shards: P records [full-length contribution to A p | double], double-buffered
                                           // like ap_gather in one process (symv_gather_bytes = one buffer)

@@ -969,10 +969,32 @@ int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pai
     for (int q = 0; q < shards; q++) {
         uint64_t R0 = 0, nloc = 0;
         partition(n, shards, q, &R0, &nloc);
-        std::vector<SymvTask> tasks;
-        std::vector<uint32_t> slot_base;
-        symv_plan(n, ncv, SS, R0, nloc, cyc, &tasks, &slot_base);
+        SymvPlan plan;
+        symv_plan(n, ncv, SS, R0, nloc, cyc, &plan);
+        const std::vector<SymvTask> &tasks = plan.tasks;
         *ntasks += tasks.size();
+        // the index the second pass walks: every task is listed once for its strip, and its run holds it
+        {
+            const uint32_t *ix = plan.index.data();
+            const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
+            std::vector<uint8_t> seen(tasks.size(), 0);
+            for (uint32_t st = 0; st < nstrips; st++)
+                for (uint32_t k = ix[plan.ix.strip_base + st]; k < ix[plan.ix.strip_base + st + 1]; k++) {
+                    const uint32_t t = ix[plan.ix.strip_tasks + k];
+                    if (t >= tasks.size() || tasks[t].strip != st || seen[t]++) return LAM_HIP_EINVAL;
+                }
+            uint64_t rp_expect = 0;
+            for (size_t t = 0; t < tasks.size(); t++) {
+                const uint32_t j = ix[plan.ix.row8 + tasks[t].row0 / 8], h = tasks[t].nrows & ~kSymvInterior;
+                if (j >= plan.nruns) return LAM_HIP_EINVAL;
+                const uint32_t *run = ix + plan.ix.runs + 5 * j;
+                if (!seen[t] || t < run[0] || t >= run[0] + run[1] || tasks[t].row0 != run[2] || h != run[3] || h % 8 != 0 && tasks[t].row0 + h != nloc ||
+                    tasks[t].rp != rp_expect || tasks[t].rp != run[4] + (t - run[0]) * h)
+                    return LAM_HIP_EINVAL;
+                rp_expect += h;
+            }
+            if (rp_expect != plan.rowpart_elems) return LAM_HIP_EINVAL;
+        }
         for (const SymvTask &t : tasks) {
             const bool interior = (t.nrows & kSymvInterior) != 0;
             const uint64_t h = t.nrows & ~kSymvInterior, c0 = (uint64_t)t.strip * SS;

@@ -1037,23 +1037,32 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
 // HBM roofline of the plain GEMV.  Two passes (round 4: second shape; the round-1 shape flushed a column
 // partial per 32 rows -- 0.55 GB written and read again per product -- and kept 32 row partials per lane):
 //   symv_task_kernel    one workgroup per TASK = a column strip (NV x 4 KiB per row, read contiguously by the
-//                       4 waves; the product uses NV = 1: 512 fp64 / 1024 fp32 columns) x a run of rows (256 for most
-//                       of the triangle, 32 for the rows dispatched last, so that the launch ends on short
-//                       tasks; shorter runs for small N).  A lane keeps the column partials of its columns in
-//                       registers over ALL rows of the task and 8 row partials at a time: every 8 rows they
+//                       4 waves; the product uses NV = 1: 512 fp64 / 1024 fp32 columns) x a run of rows (1024 for the
+//                       bulk of the triangle, 256 from 60 % of the work on, 64 for the last 8 %, so that the launch
+//                       ends on short tasks; shorter runs for small N).  A lane keeps the column partials of its
+//                       columns in registers over ALL rows of the task and 8 row partials at a time: every 8 rows they
 //                       are summed across the wave by a transposed butterfly (wave_sum8: 7 exchanged values
-//                       for 8 rows instead of 48) and parked in LDS until the task ends.  Tasks are dispatched
-//                       row block by row block, all strips of a row block side by side: whole rows stream, as
+//                       for 8 rows instead of 48) and parked in LDS, which is flushed every 256 rows.  Tasks are
+//                       dispatched row run by row run, all strips of a run side by side: whole rows stream, as
 //                       in the GEMV.  Elements left of the diagonal are masked (not even read where a whole
 //                       16-byte vector lies left of it); the diagonal counts once.
-//   symv_reduce_kernel  y[i] = sum_{strips s at or right of i} rowpart[s][i] + sum_{tasks t of i's strip}
-//                       colpart[t][i - c0], fixed order (deterministic), plus the workgroup's partial of p.y.
-// Partials: ~0.17 GB written and read per product at N=65536.  Any N (rows are padded to whole vectors with zeros,
-// p likewise).  The caller asserts symmetry (lam_hip_check_symmetry measures it).
+//   symv_reduce_kernel  y[i] = the row partials of i's row run + the column partials of the tasks of i's strip,
+//                       fixed order (deterministic), plus the workgroup's partial of p.y.
+// Partials: ~85 MB written and read per product at N=65536, indexed by task in dispatch order (see symv_reduce_kernel:
+// their stores are what separates the first pass from the rate of its loads alone).  Any N (rows are padded to whole
+// vectors with zeros, p likewise).  The caller asserts symmetry (lam_hip_check_symmetry measures it).
 // ---------------------------------------------------------------------------------------------
-constexpr int kSymvRowsMax = 256;      // rows of the tallest task (LDS row-partial buffer)
+constexpr int kSymvRowsLds = 256;      // row partials parked in LDS before they are stored (a task flushes them every 256 rows)
+constexpr int kSymvRowsMax = 2048;     // rows of the tallest task
+constexpr int kSymvListChunk = 1024;   // entries of a strip's task list the second pass stages in LDS at a time
 constexpr int kSymvReduceRows = 32;    // rows per workgroup of the second pass = p.Ap partials per product: ceil(n / 32)
-struct SymvTask { uint32_t row0, nrows, strip, slot; };   // slot: this task's row of colpart (slots of a strip are consecutive)
+struct SymvTask { uint32_t row0, nrows, strip, rp; };     // rp: where the task's row partials start in rowpart (elements)
+// What the second pass needs to find the partials, one uint32 array on the device (offsets in uint32 units):
+//   runs      5 words per row run: first task, number of tasks (the run's strips are consecutive tasks), first row, rows, and
+//             where the first task's row partials start in rowpart (the run's tasks follow at a pitch of `rows`)
+//   row8      for every 8 local rows the run they belong to (task heights are multiples of 8)
+//   strip_base / strip_tasks   per strip the list of the tasks that cover it, in task order
+struct SymvIndex { uint32_t runs, row8, strip_base, strip_tasks; };
 
 // lane exchanges of the transposed butterfly.  gfx950: v_permlane32_swap / v_permlane16_swap move both directions of a
 // halving step in one instruction (no select, no LDS crossbar); inside a 16-lane row DPP: rotation by 8 (= lane ^ 8),
@@ -1125,13 +1134,12 @@ constexpr uint32_t kSymvInterior = 0x80000000u;   // flag in SymvTask::nrows (ho
 template <typename T, int NV, bool CYC>
 __global__ void __launch_bounds__(kBlock)
 symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks, T *__restrict__ rowpart,
-                 T *__restrict__ colpart, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch, uint64_t n, uint64_t row_off,
-                 const CgScalars *sc)
+                 T *__restrict__ colpart, uint64_t lda, uint64_t ncols_vec, uint64_t n, uint64_t row_off, const CgScalars *sc)
 {
     using MV = MatVec<T>;
     using vec_t = typename MV::vec_t;
     constexpr int VEC = MV::N, CW = kBlock * VEC, SS = NV * CW;     // CW: columns the workgroup covers with one vector per lane
-    __shared__ T s_rows[kWaves][kSymvRowsMax];
+    __shared__ T s_rows[kWaves][kSymvRowsLds];
     if (sc != nullptr && sc->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SymvTask t = tasks[blockIdx.x];                                                  // row0: LOCAL row (A, rowpart); global = row_off + row0
@@ -1155,6 +1163,19 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
     // of 4 rows -- the loads of the next step's half are issued as soon as this step's half has been consumed, so a wave always
     // has 4 * NV ... 8 * NV loads in flight (a loop that drains its loads, computes its ~125 vector instructions and only then
     // issues the next ones measured 1-4 % slower, profiles/r04_symv2_probe.txt).
+    // the row partials of the last (up to) 256 rows, ending at row `end` of the task: out of LDS into rowpart (uniform call sites)
+    auto flush_rows = [&](uint32_t end) {
+        const uint32_t beg = (end - 1) & ~(uint32_t)(kSymvRowsLds - 1);
+        __syncthreads();
+        for (uint32_t r = beg + tid; r < end && r < t.nrows; r += kBlock) {
+            const uint32_t q = r - beg;
+#ifdef LAM_SYMV_PROBE_NO_PARTIAL_STORES      /* tools/symv2_probe only: what the partial stores cost (results are wrong without them) */
+            if (s_rows[0][q] == (T)123.456)
+#endif
+            __builtin_nontemporal_store((s_rows[0][q] + s_rows[1][q]) + (s_rows[2][q] + s_rows[3][q]), rowpart + (uint64_t)t.rp + r);
+        }
+        __syncthreads();
+    };
     if (interior) {
         const T *rows = A + (uint64_t)t.row0 * lda + c0;           // uniform
         const T *prow = p + grow0;
@@ -1211,7 +1232,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                         a1[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(rows + (uint64_t)(k + 4) * lda + v * CW) + tid);
             }
             const T tot = wave_sum8(racc);
-            if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
+            if ((lane & 7) == 0) s_rows[wave][(b & (kSymvRowsLds - 1)) + (lane >> 3)] = tot;
+            if (((b + 8) & (kSymvRowsLds - 1)) == 0 || b + 8 >= t.nrows) flush_rows(b + 8);
         }
     } else {
         // tasks on the rim of a row's window (the diagonal, the far end, the antipode), ragged strips and row runs: per element
@@ -1249,7 +1271,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                 racc[k] = r;
             }
             const T tot = wave_sum8(racc);
-            if ((lane & 7) == 0) s_rows[wave][b + (lane >> 3)] = tot;
+            if ((lane & 7) == 0) s_rows[wave][(b & (kSymvRowsLds - 1)) + (lane >> 3)] = tot;
+            if (((b + 8) & (kSymvRowsLds - 1)) == 0 || b + 8 >= t.nrows) flush_rows(b + 8);
         }
     }
 #pragma unroll
@@ -1258,29 +1281,34 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
             vec_t out;
 #pragma unroll
             for (int i = 0; i < VEC; i++) out[i] = cacc[v][i];
-            *reinterpret_cast<vec_t *>(colpart + (uint64_t)t.slot * SS + (uint64_t)v * CW + (uint64_t)tid * VEC) = out;
+#ifdef LAM_SYMV_PROBE_NO_PARTIAL_STORES      /* tools/symv2_probe only: what the partial stores cost (results are wrong without them) */
+            if (out[0] == (T)123.456)
+#endif
+            __builtin_nontemporal_store(out, reinterpret_cast<vec_t *>(colpart + (uint64_t)blockIdx.x * SS + (uint64_t)v * CW + (uint64_t)tid * VEC));
         }
-    __syncthreads();
-    for (uint32_t r = tid; r < t.nrows; r += kBlock)
-        rowpart[(uint64_t)t.strip * row_pitch + t.row0 + r] = (s_rows[0][r] + s_rows[1][r]) + (s_rows[2][r] + s_rows[3][r]);
 }
 
-// Second pass.  32 entries of y per workgroup; the terms of an entry are dealt round-robin to 8 groups of 32 lanes (four loads
-// in flight per lane) and combined in a fixed order.  Row side: rowpart[s][i] of every strip s (a (strip, row) pair no task
-// covers keeps the zero it was allocated with) for the rows this shard owns, [row_off, row_off + nloc); column side: the
-// colpart slots of i's strip.  One shard: y is the product, `partial` its p.y per workgroup.  Several shards (dst.n > 0): the
-// entry is this shard's CONTRIBUTION to y[i], stored into its record in every shard's gather buffer; the consumer adds the
-// shards' records in shard order; the launch carries one extra workgroup (fin.active) that sums the workgroups' parts of p.Ap
-// in the fixed order of block_sum_array and writes the total behind the record (see Finalize).
+// Second pass.  32 entries of y per workgroup; the terms of an entry are dealt round-robin to 8 groups of 32 lanes and combined
+// in a fixed order.  Both kinds of partial are indexed BY TASK, in dispatch order -- rowpart[task][row of the run],
+// colpart[task][column of the strip] --, so that the tasks in flight together write next to each other: with the partials
+// laid out by strip (a 4-KiB column partial every ~1 MiB, a 2-KiB row partial every 512 KiB) the first pass ran up to 10 %
+// slower depending on where the buffers happened to be placed (2.57 ... 2.85 ms for the same launch at N=65536; with every task
+// writing ONE slot 2.52 ... 2.61: profiles/r04_symv2_probe.txt) -- 1 % of the traffic, but scattered over as many pages as
+// tasks.  Row side: the tasks of the row's run (consecutive) for the rows this shard owns, [row_off, row_off + nloc); column
+// side: the tasks listed for the column's strip.  One shard: y is the product, `partial` its p.y per workgroup.  Several shards
+// (dst.n > 0): the entry is this shard's CONTRIBUTION to y[i], stored into its record in every shard's gather buffer; the
+// consumer adds the shards' records in shard order; the launch carries one extra workgroup (fin.active) that sums the
+// workgroups' parts of p.Ap in the fixed order of block_sum_array and writes the total behind the record (see Finalize).
 template <typename T, int NV>
 __global__ void __launch_bounds__(kBlock)
-symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const uint32_t *__restrict__ slot_base,
-                   const T *__restrict__ p, T *__restrict__ y, double *__restrict__ partial, uint64_t n, uint64_t row_pitch,
-                   uint32_t nstrips, uint64_t row_off, uint64_t nloc, PtrList dst, Finalize fin, const CgScalars *sc)
+symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const uint32_t *__restrict__ index, SymvIndex ix,
+                   const T *__restrict__ p, T *__restrict__ y, double *__restrict__ partial, uint64_t n, uint64_t row_off,
+                   uint64_t nloc, PtrList dst, Finalize fin, const CgScalars *sc)
 {
     constexpr int SS = NV * kBlock * MatVec<T>::N, RB = kSymvReduceRows, G = kBlock / RB;
     __shared__ T s[G][RB];
     __shared__ double s_dot[RB];
+    __shared__ uint32_t s_list[kSymvListChunk];
     if (sc != nullptr && sc->stop) return;
     if (is_reducer_block(fin)) {                        // several shards: the shard's part of p.Ap as ONE number, inside this launch
         reduce_partials(partial, (int)compute_blocks(fin), fin, s_dot);
@@ -1289,26 +1317,43 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
     const int l = threadIdx.x % RB, g = threadIdx.x / RB;
     const uint64_t i = (uint64_t)blockIdx.x * RB + l;
     T acc = (T)0;
-    if (i < n) {
-        if (i >= row_off && i < row_off + nloc) {
-            const uint64_t il = i - row_off;
-            uint32_t q = g;
-            for (; q + 3 * G < nstrips; q += 4 * G) {
-                const T a0 = rowpart[(uint64_t)q * row_pitch + il], a1 = rowpart[(uint64_t)(q + G) * row_pitch + il];
-                const T a2 = rowpart[(uint64_t)(q + 2 * G) * row_pitch + il], a3 = rowpart[(uint64_t)(q + 3 * G) * row_pitch + il];
-                acc += (a0 + a1) + (a2 + a3);
-            }
-            for (; q < nstrips; q += G) acc += rowpart[(uint64_t)q * row_pitch + il];
-        }
-        const uint32_t s0 = (uint32_t)(i / SS), e = slot_base[s0 + 1];
-        const uint64_t col = i - (uint64_t)s0 * SS;
-        uint32_t k = slot_base[s0] + g;
-        for (; k + 3 * G < e; k += 4 * G) {
-            const T a0 = colpart[(uint64_t)k * SS + col], a1 = colpart[(uint64_t)(k + G) * SS + col];
-            const T a2 = colpart[(uint64_t)(k + 2 * G) * SS + col], a3 = colpart[(uint64_t)(k + 3 * G) * SS + col];
+    if (i < n && i >= row_off && i < row_off + nloc) {
+        const uint64_t il = i - row_off;
+        const uint32_t *run = index + ix.runs + 5 * index[ix.row8 + (il >> 3)];
+        const uint32_t cnt = run[1], h = run[3];
+        const T *src = rowpart + (uint64_t)run[4] + (il - run[2]);
+        uint32_t q = g;
+        for (; q + 3 * G < cnt; q += 4 * G) {
+            const T a0 = src[(uint64_t)q * h], a1 = src[(uint64_t)(q + G) * h];
+            const T a2 = src[(uint64_t)(q + 2 * G) * h], a3 = src[(uint64_t)(q + 3 * G) * h];
             acc += (a0 + a1) + (a2 + a3);
         }
-        for (; k < e; k += G) acc += colpart[(uint64_t)k * SS + col];
+        for (; q < cnt; q += G) acc += src[(uint64_t)q * h];
+    }
+    // column side: the workgroup's 32 columns lie in ONE strip (32 divides the strip width), so its task list is staged in LDS
+    // once per 1024 entries -- a load of the list in front of every load of a partial doubled the chain of memory latencies that
+    // this pass is made of at small N
+    {
+        const uint32_t s0 = (uint32_t)(((uint64_t)blockIdx.x * RB) / SS);
+        const uint32_t lb = index[ix.strip_base + s0], le = index[ix.strip_base + s0 + 1];
+        const uint32_t *list = index + ix.strip_tasks;
+        const T *src = colpart + (i - (uint64_t)s0 * SS);
+        for (uint32_t base = lb; base < le; base += kSymvListChunk) {
+            const uint32_t cnt = le - base < (uint32_t)kSymvListChunk ? le - base : (uint32_t)kSymvListChunk;
+            __syncthreads();                                  // the previous chunk has been consumed
+            for (uint32_t q = threadIdx.x; q < cnt; q += kBlock) s_list[q] = list[base + q];
+            __syncthreads();
+            if (i < n) {
+                uint32_t k = g;
+                for (; k + 7 * G < cnt; k += 8 * G) {
+                    T a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) a[u] = src[(uint64_t)s_list[k + u * G] * SS];
+                    acc += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+                }
+                for (; k < cnt; k += G) acc += src[(uint64_t)s_list[k] * SS];
+            }
+        }
     }
     s[g][l] = acc;
     __syncthreads();

@@ -5,30 +5,57 @@
 namespace {
 
 // ---- typed implementation ----------------------------------------------------------------------
-// The symmetric product's task list for one shard (rows [R0, R0 + nloc) of an n x n matrix, strips of SS columns, ncv = columns a
-// row holds in whole vectors): pure host arithmetic, shared by the launcher below and by lam_hip_debug_symv_plan (a CPU test
-// counts that every directed pair (i <- j) is produced exactly once and that no task flagged interior has an unused element).
-void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc, bool cyc, std::vector<SymvTask> *out_tasks,
-               std::vector<uint32_t> *out_slot_base)
+// The symmetric product's plan for one shard (rows [R0, R0 + nloc) of an n x n matrix, strips of SS columns, ncv = columns a row
+// holds in whole vectors): pure host arithmetic, shared by the launcher below and by lam_hip_debug_symv_plan (a CPU test counts
+// that every directed pair (i <- j) is produced exactly once and that no task flagged interior has an unused element).
+// tasks: in dispatch order -- row run by row run, the strips of a run side by side --, which is also the order of the partials.
+struct SymvPlan {
+    std::vector<SymvTask> tasks;
+    std::vector<uint32_t> index;      // the device-side index (SymvIndex) ...
+    SymvIndex ix;                     // ... and where its parts start
+    uint32_t nruns = 0;
+    uint64_t rowpart_elems = 0;       // row partials of all tasks (one per row of every task)
+};
+void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc, bool cyc, SymvPlan *out)
 {
     const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
     const uint64_t H = (n - 1) / 2;
-    uint64_t tall = cyc ? 8 : 32, split;
+    // Task heights.  The partial stores are what separates the first pass from the rate of its loads alone (190 MB of them cost
+    // 4-10 % at N=65536, profiles/r04_symv2_probe.txt), and a task stores SS column partials whatever its height: tall tasks for
+    // the bulk, shorter ones only for what is dispatched last (the launch hands out tasks in list order and should end on short
+    // ones: the last ~8 % of the work).  One shard (the triangle: row r holds n - r elements): `tall` rows up to the row below
+    // which 60 % of the work lies, tall / 4 up to 92 %, tall / 16 after; tall = 1024 from N = 65536 on, N / 64 below; N < 16384:
+    // two classes, tall up to row 0.65 n and tall / 8 after (a
+    // launch wants some thousands of tasks).  Several shards (every row holds n / 2 elements): tall so that a shard has >= ~4000
+    // tasks, tall / 4 for its last 8 % of rows.
+    uint64_t tall = 32, mid_from, small_from;
+    bool two_classes = cyc;
     if (!cyc) {
-        while (tall < (uint64_t)kSymvRowsMax && tall * 64 <= n) tall *= 2;
-        split = (uint64_t)(0.65 * (double)n) / kSymvRowsMax * kSymvRowsMax;
+        while (tall < 1024 && tall * 64 <= n) tall *= 2;
+        mid_from = (uint64_t)((1.0 - std::sqrt(0.40)) * (double)n);
+        small_from = (uint64_t)((1.0 - std::sqrt(0.08)) * (double)n);
+        if (n < 16384) {                                           // small systems: the second pass's fixed cost counts, fewer tasks win
+            two_classes = true;
+            mid_from = small_from = (uint64_t)(0.65 * (double)n);
+        }
     } else {
+        tall = 8;
         const uint64_t strips_per_run = n / 2 / SS + 2;
-        while (tall < (uint64_t)kSymvRowsMax && nloc * strips_per_run / (2 * tall) >= 6000) tall *= 2;
-        split = (uint64_t)(0.85 * (double)nloc) / kSymvRowsMax * kSymvRowsMax;
+        while (tall < 1024 && nloc * strips_per_run / (2 * tall) >= 4000) tall *= 2;
+        mid_from = small_from = (uint64_t)(0.92 * (double)nloc);
     }
-    const uint64_t small = tall / 8 < 8 ? 8 : tall / 8;
+    const uint64_t mid = std::max<uint64_t>(8, cyc ? tall / 4 : (two_classes ? tall / 8 : tall / 4));
+    const uint64_t small = two_classes ? mid : std::max<uint64_t>(8, tall / 16);
+    mid_from = mid_from / tall * tall;                            // classes start on multiples of the height before them
+    small_from = std::max(mid_from, small_from / mid * mid);
     auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };   // closed intervals
-    std::vector<SymvTask> &tasks = *out_tasks;
-    std::vector<std::vector<SymvTask>> per_strip(nstrips);
+    std::vector<SymvTask> &tasks = out->tasks;
+    std::vector<uint32_t> runs, row8((nloc + 7) / 8, 0);
+    std::vector<std::vector<uint32_t>> per_strip(nstrips);
     for (uint64_t r = 0; r < nloc;) {
-        const uint64_t h = std::min<uint64_t>(nloc - r, r < split ? tall : small);
+        const uint64_t h = std::min<uint64_t>(nloc - r, r < mid_from ? tall : (r < small_from ? mid : small));
         const uint64_t ga = R0 + r, gb = ga + h;                   // global rows [ga, gb)
+        const uint32_t run = (uint32_t)(runs.size() / 5), first = (uint32_t)tasks.size();
         for (uint32_t st = 0; st < nstrips; st++) {
             const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;     // real columns [c0, c1]
             bool needed, interior = c0 + SS <= n && h % 8 == 0;       // the whole strip inside the matrix: no padding column
@@ -46,19 +73,26 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
                 interior = interior && in;
             }
             if (!needed) continue;
-            per_strip[st].push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u), st, 0});
+            per_strip[st].push_back((uint32_t)tasks.size());
+            tasks.push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u), st, (uint32_t)out->rowpart_elems});
+            out->rowpart_elems += h;
         }
+        runs.insert(runs.end(), {first, (uint32_t)tasks.size() - first, (uint32_t)r, (uint32_t)h, tasks.size() > first ? tasks[first].rp : 0u});
+        for (uint64_t q = r / 8; q < (r + h + 7) / 8; q++) row8[q] = run;
         r += h;
     }
-    out_slot_base->assign(nstrips + 1, 0);
-    for (uint32_t st = 0; st < nstrips; st++) {
-        (*out_slot_base)[st + 1] = (*out_slot_base)[st] + (uint32_t)per_strip[st].size();
-        for (size_t k = 0; k < per_strip[st].size(); k++) {
-            per_strip[st][k].slot = (*out_slot_base)[st] + (uint32_t)k;
-            tasks.push_back(per_strip[st][k]);
-        }
-    }
-    std::stable_sort(tasks.begin(), tasks.end(), [](const SymvTask &a, const SymvTask &b) { return a.row0 < b.row0; });
+    out->nruns = (uint32_t)(runs.size() / 5);
+    std::vector<uint32_t> &index = out->index;
+    out->ix.runs = 0;
+    index = runs;
+    out->ix.row8 = (uint32_t)index.size();
+    index.insert(index.end(), row8.begin(), row8.end());
+    out->ix.strip_base = (uint32_t)index.size();
+    uint32_t acc = 0;
+    for (uint32_t st = 0; st < nstrips; st++) { index.push_back(acc); acc += (uint32_t)per_strip[st].size(); }
+    index.push_back(acc);
+    out->ix.strip_tasks = (uint32_t)index.size();
+    for (uint32_t st = 0; st < nstrips; st++) index.insert(index.end(), per_strip[st].begin(), per_strip[st].end());
 }
 
 template <typename TA, typename TV>
@@ -176,26 +210,24 @@ struct Impl {
     template <int NV>
     static int build_symv_tasks(lam_hip_ctx *c, ShardBase &s, bool cyc)
     {
-        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec(), nloc = s.nrows;
-        const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
-        const uint64_t row_pitch = (nloc + 63) / 64 * 64;
-        std::vector<SymvTask> tasks;
-        std::vector<uint32_t> slot_base;
-        symv_plan(n, ncv, SS, s.row0, nloc, cyc, &tasks, &slot_base);
+        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec();
+        SymvPlan plan;
+        symv_plan(n, ncv, SS, s.row0, s.nrows, cyc, &plan);
+        const std::vector<SymvTask> &tasks = plan.tasks;
         if (tasks.empty()) return fail(c, LAM_HIP_EINVAL, "symmetric product: no tasks");
         // all four or none: a later failure must not leave the earlier buffers behind
         DevBuf t, rp, cp, sb;
         HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
-        HIPCHK(c, hipMalloc(&rp.p, (size_t)nstrips * row_pitch * sizeof(TA)));
+        if (plan.rowpart_elems >> 32) return fail(c, LAM_HIP_EINVAL, "symmetric product: too many row partials for 32-bit offsets");
+        HIPCHK(c, hipMalloc(&rp.p, (size_t)plan.rowpart_elems * sizeof(TA)));
         HIPCHK(c, hipMalloc(&cp.p, tasks.size() * SS * sizeof(TA)));
-        HIPCHK(c, hipMalloc(&sb.p, slot_base.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&sb.p, plan.index.size() * sizeof(uint32_t)));
         HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(sb.p, slot_base.data(), slot_base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        // a (strip, row) pair no task covers keeps this zero (the second pass adds the row partials of ALL strips); columns
-        // behind the end of a ragged strip are never written by a task and never read by the second pass
-        HIPCHK(c, hipMemsetAsync(rp.p, 0, (size_t)nstrips * row_pitch * sizeof(TA), s.stream));
+        HIPCHK(c, hipMemcpy(sb.p, plan.index.data(), plan.index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // columns behind the end of a ragged strip are never written by a task: the second pass does not read them either
         HIPCHK(c, hipMemsetAsync(cp.p, 0, tasks.size() * SS * sizeof(TA), s.stream));
-        s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p; s.symv_slot_base = sb.as<uint32_t>();
+        s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p; s.symv_index = sb.as<uint32_t>();
+        s.symv_ix = plan.ix;
         t.p = rp.p = cp.p = sb.p = nullptr;
         s.symv_ntasks = (int)tasks.size();
         return 0;
@@ -207,20 +239,18 @@ struct Impl {
                               const Finalize &fin)
     {
         const bool cyc = dst.n > 0;
-        const uint64_t n = c->n, SS = (uint64_t)NV * kBlock * VEC, ncv = c->ncols_vec();
-        const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
-        const uint64_t row_pitch = (s.nrows + 63) / 64 * 64;
+        const uint64_t n = c->n, ncv = c->ncols_vec();
         if (s.symv_tasks == nullptr) LAMCHK(build_symv_tasks<NV>(c, s, cyc));
         if (cyc)
             hipLaunchKernelGGL((symv_task_kernel<TA, NV, true>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
-                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, n, s.row0, sc);
+                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
         else
             hipLaunchKernelGGL((symv_task_kernel<TA, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
-                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, row_pitch, n, s.row0, sc);
+                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n) + (fin.active ? 1 : 0)), dim3(kBlock), 0, s.stream,
-                           (const TA *)s.symv_rowpart, (const TA *)s.symv_colpart, (const uint32_t *)s.symv_slot_base, (const TA *)p, (TA *)y,
-                           partial, n, row_pitch, nstrips, s.row0, s.nrows, dst, fin, sc);
+                           (const TA *)s.symv_rowpart, (const TA *)s.symv_colpart, (const uint32_t *)s.symv_index, s.symv_ix, (const TA *)p, (TA *)y,
+                           partial, n, s.row0, s.nrows, dst, fin, sc);
         HIPCHK(c, hipGetLastError());
         c->n_launch += 2;
         return 0;
@@ -391,12 +421,12 @@ void free_shard(ShardBase &s, bool keep_matrix = false)
     const size_t keepCap = keep_matrix ? s.A_capacity : 0;
     if (keep_matrix) s.A = nullptr;
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
-                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.symv_slot_base, s.symv_gather, s.part_aux};
+                    s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.symv_index, s.symv_gather, s.part_aux};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     s.r_full = s.ap_gather = s.symv_rowpart = s.symv_colpart = s.symv_gather = nullptr;
     s.symv_gather_bytes = 0;
     s.symv_tasks = nullptr;
-    s.symv_slot_base = nullptr;
+    s.symv_index = nullptr;
     s.symv_ntasks = 0;
     if (s.sc_host) (void)hipHostFree(s.sc_host);
     if (s.host_flags) (void)hipHostFree(s.host_flags);

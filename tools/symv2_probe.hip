@@ -134,11 +134,13 @@ template <typename T>
 struct Plan {
     std::string name;
     int NV;
+    unsigned lds_extra = 0;      // bytes of idle dynamic LDS per workgroup of the first pass: caps the workgroups per CU (spec NV = KiB * 100 + NV)
     std::vector<std::pair<int, double>> sched;     // task height, up to which row fraction
     uint32_t nstrips = 0, ntasks = 0;
     T *rowpart = nullptr, *colpart = nullptr;
     Task *dt = nullptr;
-    uint32_t *dsb = nullptr;
+    uint32_t *dsb = nullptr;      // the second pass's index (lam::SymvIndex)
+    lam::SymvIndex ix = {};
     std::vector<double> t1, t12;
     double err = 0;
 };
@@ -147,13 +149,13 @@ template <typename T>
 bool pass1(const Plan<T> &pl, const T *A, const T *p, uint64_t n, uint64_t lda, uint64_t ncols_vec, uint64_t row_pitch)
 {
     if (g_shard_P > 0) {
-        const uint64_t R0 = g_shard_q * (n / g_shard_P), rp = (n / g_shard_P + 63) / 64 * 64;
-        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, rp, n, R0, (const lam::CgScalars *)nullptr);
-        else hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, rp, n, R0, (const lam::CgScalars *)nullptr);
+        const uint64_t R0 = g_shard_q * (n / g_shard_P);
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, R0, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, R0, (const lam::CgScalars *)nullptr);
         return true;
     }
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, false>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, false>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, row_pitch, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, false>), dim3(pl.ntasks), dim3(kBlock), pl.lds_extra, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, false>), dim3(pl.ntasks), dim3(kBlock), pl.lds_extra, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -166,13 +168,13 @@ bool pass2(const Plan<T> &pl, const T *p, T *y, double *partial, uint64_t n, uin
     lam::Finalize nofin;
     nofin.active = 0; nofin.mail = 0; nofin.seq = 0; nofin.dst.n = 0; nofin.slot = 0; nofin.host_err = nullptr;
     if (g_shard_P > 0) {
-        const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc, rp = (nloc + 63) / 64 * 64;
-        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
-        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, rp, pl.nstrips, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
+        const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc;
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
         return true;
     }
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, p, y, partial, n, row_pitch, pl.nstrips, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -197,12 +199,18 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
     double maxref = 0;
     for (uint64_t i = 0; i < n; i++) maxref = std::max(maxref, std::fabs((double)hr[i]));
 
+    if (const char *pad = getenv("SYMV2_PAD_MB")) {        // an idle allocation between the matrix and the plans' buffers (placement experiments)
+        void *dummy = nullptr;
+        CHK(hipMalloc(&dummy, (size_t)atol(pad) << 20));
+    }
     std::vector<Plan<T>> plans;
     for (const auto &spec : specs) {       // NV:h1@f1,h2@f2,...,hlast
         Plan<T> pl;
         pl.name = spec;
         char sched[256] = "";
         if (sscanf(spec.c_str(), "%d:%255s", &pl.NV, sched) != 2) { printf("bad spec %s\n", spec.c_str()); return 1; }
+        pl.lds_extra = (unsigned)(pl.NV / 100) * 1024u;
+        pl.NV %= 100;
         for (char *tok = strtok(sched, ","); tok; tok = strtok(nullptr, ",")) {
             int hgt = 0; double f = 2.0;
             if (sscanf(tok, "%d@%lf", &hgt, &f) < 1 || hgt % 8 || hgt > kRowsMax || hgt <= 0) { printf("bad schedule %s\n", tok); return 1; }
@@ -210,63 +218,62 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
         }
         const uint64_t SS = (uint64_t)pl.NV * kBlock * VEC;
         pl.nstrips = (uint32_t)((ncols_vec + SS - 1) / SS);
+        // tasks in dispatch order -- row run by row run, the strips of a run side by side -- and the second pass's index, as the
+        // library's planner builds them (lam_launch.h, symv_plan), but with this probe's schedules of task heights
         std::vector<Task> tasks;
-        std::vector<uint32_t> slot_base(pl.nstrips + 1, 0);
-        // row boundaries of the schedule classes, aligned so that every class starts on a multiple of the largest height
+        std::vector<uint32_t> runs, index;
+        uint64_t rp_elems = 0;
+        const bool cyc = g_shard_P > 0;
+        const uint64_t nloc = cyc ? n / g_shard_P : n, R0 = cyc ? g_shard_q * nloc : 0, H = (n - 1) / 2;
+        std::vector<uint32_t> row8((nloc + 7) / 8, 0);
+        std::vector<std::vector<uint32_t>> per_strip(pl.nstrips);
         std::vector<uint64_t> upto;
-        for (auto &c : pl.sched) upto.push_back(c.second >= 1.0 ? n : (uint64_t)(c.second * (double)n) / kRowsMax * kRowsMax);
-        if (g_shard_P > 0) {
-            // one row shard, the library's cyclic half windows (lam_launch.h, build_symv_tasks); the schedule's fractions are of the shard's rows
-            const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc, H = (n - 1) / 2;
-            std::vector<uint64_t> up;
-            for (auto &c : pl.sched) up.push_back(c.second >= 1.0 ? nloc : (uint64_t)(c.second * (double)nloc) / kRowsMax * kRowsMax);
-            auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };
-            std::vector<std::vector<Task>> per_strip(pl.nstrips);
-            for (uint64_t r = 0; r < nloc;) {
-                size_t cls = 0;
-                while (cls + 1 < pl.sched.size() && r >= up[cls]) cls++;
-                const uint64_t hgt = std::min<uint64_t>(nloc - r, (uint64_t)pl.sched[cls].first), ga = R0 + r, gb = ga + hgt;
-                for (uint32_t st = 0; st < pl.nstrips; st++) {
-                    const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;
-                    if (!(meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2))) continue;
+        for (auto &c : pl.sched) upto.push_back(c.second >= 1.0 ? nloc : (uint64_t)(c.second * (double)nloc) / pl.sched[0].first * pl.sched[0].first);
+        auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };
+        for (uint64_t r = 0; r < nloc;) {
+            size_t cls = 0;
+            while (cls + 1 < pl.sched.size() && r >= upto[cls]) cls++;
+            const uint64_t hgt = std::min<uint64_t>(nloc - r, (uint64_t)pl.sched[cls].first), ga = R0 + r, gb = ga + hgt;
+            const uint32_t run = (uint32_t)(runs.size() / 5), first = (uint32_t)tasks.size();
+            for (uint32_t st = 0; st < pl.nstrips; st++) {
+                const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;
+                bool needed, interior = c0 + SS <= n && hgt % 8 == 0;
+                if (!cyc) { needed = c1 >= ga; interior = interior && c0 >= gb; }
+                else {
+                    needed = meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2);
                     bool in = false;
                     for (uint64_t k2 = 0; k2 < 2; k2++) {
                         const uint64_t u0 = c0 + k2 * n, u1 = c0 + SS - 1 + k2 * n;
                         in = in || (u0 >= gb && u1 - ga <= H);
                     }
-                    const bool interior = c0 + SS <= n && hgt % 8 == 0 && in;
-                    per_strip[st].push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), st, 0});
+                    interior = interior && in;
                 }
-                r += hgt;
+                if (!needed) continue;
+                per_strip[st].push_back((uint32_t)tasks.size());
+                tasks.push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), st, (uint32_t)rp_elems});
+                rp_elems += hgt;
             }
-            for (uint32_t st = 0; st < pl.nstrips; st++) {
-                slot_base[st + 1] = slot_base[st] + (uint32_t)per_strip[st].size();
-                for (size_t k2 = 0; k2 < per_strip[st].size(); k2++) { per_strip[st][k2].slot = slot_base[st] + (uint32_t)k2; tasks.push_back(per_strip[st][k2]); }
-            }
-        } else
-        for (uint32_t s = 0; s < pl.nstrips; s++) {
-            const uint64_t rows = std::min<uint64_t>(n, (uint64_t)s * SS + SS);
-            uint32_t k = 0;
-            for (uint64_t r = 0; r < rows;) {
-                size_t cls = 0;
-                while (cls + 1 < pl.sched.size() && r >= upto[cls]) cls++;
-                const uint64_t hgt = std::min<uint64_t>(rows - r, (uint64_t)pl.sched[cls].first);
-                const bool interior = (uint64_t)s * SS + SS <= n && hgt % 8 == 0 && (uint64_t)s * SS >= r + hgt;   // as the library
-                tasks.push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), s, slot_base[s] + k});
-                k++;
-                r += hgt;
-            }
-            slot_base[s + 1] = slot_base[s] + k;
+            runs.insert(runs.end(), {first, (uint32_t)tasks.size() - first, (uint32_t)r, (uint32_t)hgt, tasks.size() > first ? tasks[first].rp : 0u});
+            for (uint64_t q = r / 8; q < (r + hgt + 7) / 8; q++) row8[q] = run;
+            r += hgt;
         }
-        // row-major: all strips of a row block run side by side (whole rows stream, like the GEMV)
-        std::stable_sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.row0 < b.row0; });
+        pl.ix.runs = 0;
+        index = runs;
+        pl.ix.row8 = (uint32_t)index.size();
+        index.insert(index.end(), row8.begin(), row8.end());
+        pl.ix.strip_base = (uint32_t)index.size();
+        uint32_t accn = 0;
+        for (uint32_t st = 0; st < pl.nstrips; st++) { index.push_back(accn); accn += (uint32_t)per_strip[st].size(); }
+        index.push_back(accn);
+        pl.ix.strip_tasks = (uint32_t)index.size();
+        for (uint32_t st = 0; st < pl.nstrips; st++) index.insert(index.end(), per_strip[st].begin(), per_strip[st].end());
         pl.ntasks = (uint32_t)tasks.size();
-        CHK(hipMalloc(&pl.rowpart, (size_t)pl.nstrips * row_pitch * sizeof(T))); CHK(hipMalloc(&pl.colpart, (size_t)pl.ntasks * SS * sizeof(T)));
-        CHK(hipMalloc(&pl.dt, tasks.size() * sizeof(Task))); CHK(hipMalloc(&pl.dsb, slot_base.size() * 4));
+        CHK(hipMalloc(&pl.rowpart, (size_t)rp_elems * sizeof(T))); CHK(hipMalloc(&pl.colpart, (size_t)pl.ntasks * SS * sizeof(T)));
+        CHK(hipMalloc(&pl.dt, tasks.size() * sizeof(Task))); CHK(hipMalloc(&pl.dsb, index.size() * 4));
         CHK(hipMemcpy(pl.dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
-        CHK(hipMemcpy(pl.dsb, slot_base.data(), slot_base.size() * 4, hipMemcpyHostToDevice));
-        CHK(hipMemset(pl.colpart, g_shard_P > 0 ? 0 : 0xff, (size_t)pl.ntasks * SS * sizeof(T)));     // NaNs: every slot the reduce reads must have been written
-        CHK(hipMemset(pl.rowpart, 0, (size_t)pl.nstrips * row_pitch * sizeof(T)));       // (strip, row) pairs no task covers stay zero
+        CHK(hipMemcpy(pl.dsb, index.data(), index.size() * 4, hipMemcpyHostToDevice));
+        CHK(hipMemset(pl.colpart, 0xff, (size_t)pl.ntasks * SS * sizeof(T)));     // NaNs: every partial the second pass reads must have been written
+        CHK(hipMemset(pl.rowpart, 0xff, (size_t)rp_elems * sizeof(T)));
         if (!pass1(pl, A, p, n, lda, ncols_vec, row_pitch) || !pass2(pl, p, y, partial, n, row_pitch)) { printf("shape of %s not compiled in\n", spec.c_str()); return 1; }
         CHK(hipDeviceSynchronize());
         CHK(hipMemcpy(h.data(), y, n * sizeof(T), hipMemcpyDeviceToHost));
@@ -279,23 +286,29 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
     std::vector<double> tf;
     for (int r = 0; r < rounds; r++) {
         tf.push_back(time_once_ms(full, 5));
+        if (getenv("SYMV2_REVERSE")) std::reverse(plans.begin(), plans.end());     // time the plans in the opposite order (allocation order stays)
         for (auto &pl : plans) {
             pl.t1.push_back(time_once_ms([&] { pass1(pl, A, p, n, lda, ncols_vec, row_pitch); }, 5));
             pl.t12.push_back(time_once_ms([&] { pass1(pl, A, p, n, lda, ncols_vec, row_pitch); pass2(pl, p, y, partial, n, row_pitch); }, 5));
         }
     }
     if (getenv("SYMV2_READONLY")) {
+        // ... at several occupancies: dynamic LDS the kernel does not use caps the workgroups per CU (160 KiB of LDS: 0 -> the register
+        // limit, 32 KiB -> 5 workgroups = 5 waves per SIMD, 40 -> 4, 53 -> 3, 80 -> 2)
         for (auto &pl : plans) {
-            std::vector<double> t;
-            auto f = [&] {
-                if (pl.NV == 1) hipLaunchKernelGGL((pattern_read_kernel<T, 1>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, pl.dt, y, lda);
-                else hipLaunchKernelGGL((pattern_read_kernel<T, 2>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A, pl.dt, y, lda);
-            };
-            for (int r = 0; r < rounds; r++) t.push_back(time_once_ms(f, 5));
-            std::sort(t.begin(), t.end());
-            printf("%-44s  the tasks' loads alone (no arithmetic): min %6.3f med %6.3f ms\n", pl.name.c_str(), t[0], t[t.size() / 2]);
+            for (unsigned lds_kib : {0u, 32u, 40u, 53u, 80u}) {
+                std::vector<double> t;
+                auto f = [&] {
+                    if (pl.NV == 1) hipLaunchKernelGGL((pattern_read_kernel<T, 1>), dim3(pl.ntasks), dim3(kBlock), lds_kib * 1024, g_stream, A, pl.dt, y, lda);
+                    else hipLaunchKernelGGL((pattern_read_kernel<T, 2>), dim3(pl.ntasks), dim3(kBlock), lds_kib * 1024, g_stream, A, pl.dt, y, lda);
+                };
+                for (int r = 0; r < rounds; r++) t.push_back(time_once_ms(f, 5));
+                std::sort(t.begin(), t.end());
+                printf("%-44s  the tasks' loads alone (no arithmetic), %2u KiB of idle LDS per workgroup: min %6.3f med %6.3f ms\n", pl.name.c_str(), lds_kib, t[0], t[t.size() / 2]);
+            }
         }
     }
+    if (getenv("SYMV2_REVERSE") && rounds % 2) std::reverse(plans.begin(), plans.end());
     auto stat = [](std::vector<double> v, double *mn, double *med) { std::sort(v.begin(), v.end()); *mn = v[0]; *med = v[v.size() / 2]; };
     const double gb_full = (double)sizeof(T) * n * n / 1e9, gb_tri = (gb_full / 2 + (double)sizeof(T) * n / 2 / 1e9) / (g_shard_P > 0 ? (double)g_shard_P : 1.0);
     if (g_shard_P > 0) printf("shard %llu of %llu: rows [%llu, %llu), cyclic half windows; its bytes = %.3f GB\n", (unsigned long long)g_shard_q, (unsigned long long)g_shard_P,
@@ -324,6 +337,14 @@ int main(int argc, char **argv)
     const uint64_t n = strtoull(argv[1], nullptr, 10);
     const bool f32 = !strcmp(argv[2], "f32");
     if (getenv("SYMV2_STREAM")) CHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<double, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<double, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<float, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<float, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pattern_read_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pattern_read_kernel<double, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pattern_read_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)pattern_read_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (const char *sh = getenv("SYMV2_SHARD")) { unsigned long long q = 0, P = 0; if (sscanf(sh, "%llu/%llu", &q, &P) == 2 && P > 0 && q < P && n % P == 0) { g_shard_q = q; g_shard_P = P; } }
     const int rounds = atoi(argv[3]);
     std::vector<std::string> specs;
