@@ -1037,8 +1037,8 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
 // HBM roofline of the plain GEMV.  Two passes (round 4: second shape; the round-1 shape flushed a column
 // partial per 32 rows -- 0.55 GB written and read again per product -- and kept 32 row partials per lane):
 //   symv_task_kernel    one workgroup per TASK = a column strip (NV x 4 KiB per row, read contiguously by the
-//                       4 waves; the product uses NV = 1: 512 fp64 / 1024 fp32 columns) x a run of rows (1024 for the
-//                       bulk of the triangle, 256 from 60 % of the work on, 64 for the last 8 %, so that the launch
+//                       4 waves; the product uses NV = 1: 512 fp64 / 1024 fp32 columns) x a run of rows (2048 for the
+//                       bulk of the triangle, 512 from 60 % of the work on, 64 for the last 8 %, so that the launch
 //                       ends on short tasks; shorter runs for small N).  A lane keeps the column partials of its
 //                       columns in registers over ALL rows of the task and 8 row partials at a time: every 8 rows they
 //                       are summed across the wave by a transposed butterfly (wave_sum8: 7 exchanged values
@@ -1048,7 +1048,7 @@ gemv_mfma_bf16_kernel(GemvArgs<__hip_bfloat16, float> a)
 //                       16-byte vector lies left of it); the diagonal counts once.
 //   symv_reduce_kernel  y[i] = the row partials of i's row run + the column partials of the tasks of i's strip,
 //                       fixed order (deterministic), plus the workgroup's partial of p.y.
-// Partials: ~85 MB written and read per product at N=65536, indexed by task in dispatch order (see symv_reduce_kernel:
+// Partials: ~70 MB written and read per product at N=65536, indexed by task in dispatch order (see symv_reduce_kernel:
 // their stores are what separates the first pass from the rate of its loads alone).  Any N (rows are padded to whole
 // vectors with zeros, p likewise).  The caller asserts symmetry (lam_hip_check_symmetry measures it).
 // ---------------------------------------------------------------------------------------------

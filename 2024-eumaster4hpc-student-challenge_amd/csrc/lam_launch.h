@@ -24,7 +24,7 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
     // 4-10 % at N=65536, profiles/r04_symv2_probe.txt), and a task stores SS column partials whatever its height: tall tasks for
     // the bulk, shorter ones only for what is dispatched last (the launch hands out tasks in list order and should end on short
     // ones: the last ~8 % of the work).  One shard (the triangle: row r holds n - r elements): `tall` rows up to the row below
-    // which 60 % of the work lies, tall / 4 up to 92 %, tall / 16 after; tall = 1024 from N = 65536 on, N / 64 below; N < 16384:
+    // which 60 % of the work lies, tall / 4 up to 92 %, at most 64 after; tall = 2048 from N = 65536 on, N / 64 below; N < 16384:
     // two classes, tall up to row 0.65 n and tall / 8 after (a
     // launch wants some thousands of tasks).  Several shards (every row holds n / 2 elements): tall so that a shard has >= ~4000
     // tasks, tall / 4 for its last 8 % of rows.
@@ -32,6 +32,7 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
     bool two_classes = cyc;
     if (!cyc) {
         while (tall < 1024 && tall * 64 <= n) tall *= 2;
+        if (n >= 65536) tall = 2048;
         mid_from = (uint64_t)((1.0 - std::sqrt(0.40)) * (double)n);
         small_from = (uint64_t)((1.0 - std::sqrt(0.08)) * (double)n);
         if (n < 16384) {                                           // small systems: the second pass's fixed cost counts, fewer tasks win
@@ -45,7 +46,7 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
         mid_from = small_from = (uint64_t)(0.92 * (double)nloc);
     }
     const uint64_t mid = std::max<uint64_t>(8, cyc ? tall / 4 : (two_classes ? tall / 8 : tall / 4));
-    const uint64_t small = two_classes ? mid : std::max<uint64_t>(8, tall / 16);
+    const uint64_t small = two_classes ? mid : std::min<uint64_t>(64, std::max<uint64_t>(8, tall / 16));
     mid_from = mid_from / tall * tall;                            // classes start on multiples of the height before them
     small_from = std::max(mid_from, small_from / mid * mid);
     auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };   // closed intervals

@@ -1,4 +1,2 @@
-# several schedules, interleaved, in three processes per size (the placement of the buffers differs from process to process): pass-1 / both-pass medians in ms
-for i in 1 2 3; do tools/symv2_probe.out 32768 f64 5 1:256@0.65,32 1:1024@0.368,256@0.717,32 1:512@0.368,128@0.717,32 1:512@0.368,128@0.717,16 1:256@0.368,64@0.717,16 | awk '/pass1/{printf "%s=%s/%s ", $1, $8, $14} END{print ""}'; done
-for i in 1 2 3; do tools/symv2_probe.out 10000 f64 7 1:128@0.65,16 1:256@0.368,64@0.717,8 1:128@0.368,32@0.717,8 1:512@0.368,128@0.717,16 1:64@0.368,16@0.717,8 | awk '/pass1/{printf "%s=%s/%s ", $1, $8, $14} END{print ""}'; done
-for i in 1 2 3; do tools/symv2_probe.out 131072 f32 3 1:256@0.65,32 1:2048@0.368,512@0.717,64 1:1024@0.368,256@0.717,64 | awk '/pass1/{printf "%s=%s/%s ", $1, $8, $14} END{print ""}'; done
+# several plans, interleaved, in several processes (the placement of the buffers differs from process to process): "pass 1 / both passes" medians in ms
+for i in 1 2 3 4; do tools/symv2_probe.out 65536 f64 3 1:1024@0.368,256@0.717,64 2:1024@0.368,256@0.717,64 2:2048@0.368,512@0.717,64 1:2048@0.368,512@0.717,64 | awk '/pass1/{printf "%s=%s/%s ", $1, $8, $14} END{print ""}'; done
