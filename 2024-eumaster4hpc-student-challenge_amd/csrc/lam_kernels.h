@@ -1131,6 +1131,11 @@ __host__ __device__ __forceinline__ void symv_use(uint64_t col, uint64_t grow, u
 constexpr uint32_t kSymvInterior = 0x80000000u;   // flag in SymvTask::nrows (host: every element of the task is used by both sides,
                                                   // the whole strip lies inside the row, a whole number of 8-row steps)
 
+// Launched with kSymvLdsPerWorkgroup bytes of LDS in all (its row-partial buffer + idle dynamic LDS), i.e. THREE workgroups per
+// CU: the tasks' loads alone run at 7.22 TB/s with three workgroups per CU against 7.0 with the five its registers allow, the
+// whole pass 1-2 % faster (fewer row streams in flight at a time; profiles/r04_symv2_probe.txt).
+constexpr unsigned kSymvLdsPerWorkgroup = 53 * 1024;
+template <typename T> constexpr unsigned symv_lds_pad() { return kSymvLdsPerWorkgroup - (unsigned)sizeof(T) * kWaves * kSymvRowsLds; }
 template <typename T, int NV, bool CYC>
 __global__ void __launch_bounds__(kBlock)
 symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks, T *__restrict__ rowpart,

@@ -243,10 +243,10 @@ struct Impl {
         const uint64_t n = c->n, ncv = c->ncols_vec();
         if (s.symv_tasks == nullptr) LAMCHK(build_symv_tasks<NV>(c, s, cyc));
         if (cyc)
-            hipLaunchKernelGGL((symv_task_kernel<TA, NV, true>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
+            hipLaunchKernelGGL((symv_task_kernel<TA, NV, true>), dim3(s.symv_ntasks), dim3(kBlock), symv_lds_pad<TA>(), s.stream, (const TA *)s.A, (const TA *)p,
                                (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
         else
-            hipLaunchKernelGGL((symv_task_kernel<TA, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), 0, s.stream, (const TA *)s.A, (const TA *)p,
+            hipLaunchKernelGGL((symv_task_kernel<TA, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), symv_lds_pad<TA>(), s.stream, (const TA *)s.A, (const TA *)p,
                                (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n) + (fin.active ? 1 : 0)), dim3(kBlock), 0, s.stream,
