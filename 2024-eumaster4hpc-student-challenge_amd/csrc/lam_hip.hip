@@ -985,7 +985,7 @@ int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pai
                 }
             uint64_t rp_expect = 0;
             for (size_t t = 0; t < tasks.size(); t++) {
-                const uint32_t j = ix[plan.ix.row8 + tasks[t].row0 / 8], h = tasks[t].nrows & ~kSymvInterior;
+                const uint32_t j = ix[plan.ix.row8 + tasks[t].row0 / 8], h = tasks[t].nrows & ~kSymvFlags;
                 if (j >= plan.nruns) return LAM_HIP_EINVAL;
                 const uint32_t *run = ix + plan.ix.runs + 5 * j;
                 if (!seen[t] || t < run[0] || t >= run[0] + run[1] || tasks[t].row0 != run[2] || h != run[3] || h % 8 != 0 && tasks[t].row0 + h != nloc ||
@@ -996,8 +996,9 @@ int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pai
             if (rp_expect != plan.rowpart_elems) return LAM_HIP_EINVAL;
         }
         for (const SymvTask &t : tasks) {
-            const bool interior = (t.nrows & kSymvInterior) != 0;
-            const uint64_t h = t.nrows & ~kSymvInterior, c0 = (uint64_t)t.strip * SS;
+            const bool interior = (t.nrows & kSymvInterior) != 0, full = (t.nrows & kSymvFull) != 0;
+            const uint64_t h = t.nrows & ~kSymvFlags, c0 = (uint64_t)t.strip * SS;
+            if ((interior && !full) || (full && (c0 + SS > n || h % 8 != 0))) ++*bad_interior;   // "full": every load is made without a test
             if (t.row0 + h > nloc) return LAM_HIP_EINVAL;
             for (uint64_t r = 0; r < h; r++) {
                 const uint64_t grow = R0 + t.row0 + r;

@@ -1128,6 +1128,9 @@ __host__ __device__ __forceinline__ void symv_use(uint64_t col, uint64_t grow, u
     *row_side = d == 0 || in_window;
     *col_side = in_window;
 }
+constexpr uint32_t kSymvFull = 0x40000000u;       // flag in SymvTask::nrows (host: the whole strip lies inside the matrix and the run is a
+                                                  // whole number of 8-row steps: no load needs a test, only the products may)
+constexpr uint32_t kSymvFlags = 0xc0000000u;
 constexpr uint32_t kSymvInterior = 0x80000000u;   // flag in SymvTask::nrows (host: every element of the task is used by both sides,
                                                   // the whole strip lies inside the row, a whole number of 8-row steps)
 
@@ -1148,8 +1151,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
     if (sc != nullptr && sc->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SymvTask t = tasks[blockIdx.x];                                                  // row0: LOCAL row (A, rowpart); global = row_off + row0
-    const bool interior = (t.nrows & kSymvInterior) != 0;
-    t.nrows &= ~kSymvInterior;
+    const bool interior = (t.nrows & kSymvInterior) != 0, full = (t.nrows & kSymvFull) != 0;
+    t.nrows &= ~kSymvFlags;
     const uint64_t c0 = (uint64_t)t.strip * SS, c = c0 + (uint64_t)tid * VEC;       // this lane's columns: c + v * CW + i
     const uint64_t grow0 = row_off + t.row0;
     bool live[NV];                                                                   // columns behind the row's end: nothing to do
@@ -1181,7 +1184,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
         }
         __syncthreads();
     };
-    if (interior) {
+    auto lean_loop = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const T *rows = A + (uint64_t)t.row0 * lda + c0;           // uniform
         const T *prow = p + grow0;
         vec_t a0[4][NV], a1[4][NV];
@@ -1204,8 +1208,10 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        r = fma_tv((T)a0[k][v][i], (T)pc[v][i], r);
-                        cacc[v][i] = fma_tv((T)a0[k][v][i], pr, cacc[v][i]);
+                        bool rs = true, cs = true;
+                        if (MASKED) symv_use<CYC>(c + (uint64_t)v * CW + i, grow0 + b + k, n, &rs, &cs);
+                        if (rs) r = fma_tv((T)a0[k][v][i], (T)pc[v][i], r);
+                        if (cs) cacc[v][i] = fma_tv((T)a0[k][v][i], pr, cacc[v][i]);
                     }
                 racc[k] = r;
             }
@@ -1224,8 +1230,10 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                 for (int v = 0; v < NV; v++)
 #pragma unroll
                     for (int i = 0; i < VEC; i++) {
-                        r = fma_tv((T)a1[k][v][i], (T)pc[v][i], r);
-                        cacc[v][i] = fma_tv((T)a1[k][v][i], pr, cacc[v][i]);
+                        bool rs = true, cs = true;
+                        if (MASKED) symv_use<CYC>(c + (uint64_t)v * CW + i, grow0 + b + 4 + k, n, &rs, &cs);
+                        if (rs) r = fma_tv((T)a1[k][v][i], (T)pc[v][i], r);
+                        if (cs) cacc[v][i] = fma_tv((T)a1[k][v][i], pr, cacc[v][i]);
                     }
                 racc[4 + k] = r;
             }
@@ -1240,8 +1248,11 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
             if ((lane & 7) == 0) s_rows[wave][(b & (kSymvRowsLds - 1)) + (lane >> 3)] = tot;
             if (((b + 8) & (kSymvRowsLds - 1)) == 0 || b + 8 >= t.nrows) flush_rows(b + 8);
         }
-    } else {
-        // tasks on the rim of a row's window (the diagonal, the far end, the antipode), ragged strips and row runs: per element
+    };
+    if (interior) lean_loop(std::false_type());
+    else if (full) lean_loop(std::true_type());      // the rim of the rows' windows in full strips: the same loads, every product tested
+    else {
+        // ragged strips and row runs: every load and every product tested
         const T *Arow = A + (uint64_t)t.row0 * lda + c;
         for (uint32_t b = 0; b < t.nrows; b += 8) {
             vec_t a[8][NV];

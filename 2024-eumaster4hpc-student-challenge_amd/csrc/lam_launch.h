@@ -59,7 +59,8 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
         const uint32_t run = (uint32_t)(runs.size() / 5), first = (uint32_t)tasks.size();
         for (uint32_t st = 0; st < nstrips; st++) {
             const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;     // real columns [c0, c1]
-            bool needed, interior = c0 + SS <= n && h % 8 == 0;       // the whole strip inside the matrix: no padding column
+            const bool full = c0 + SS <= n && h % 8 == 0;             // the whole strip inside the matrix (no padding column), whole 8-row steps
+            bool needed, interior = full;
             if (!cyc) {
                 needed = c1 >= ga;                                 // some column at or right of the first row's diagonal
                 interior = interior && c0 >= gb;                   // every column right of every row
@@ -75,7 +76,7 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
             }
             if (!needed) continue;
             per_strip[st].push_back((uint32_t)tasks.size());
-            tasks.push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u), st, (uint32_t)out->rowpart_elems});
+            tasks.push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u) | (full ? kSymvFull : 0u), st, (uint32_t)out->rowpart_elems});
             out->rowpart_elems += h;
         }
         runs.insert(runs.end(), {first, (uint32_t)tasks.size() - first, (uint32_t)r, (uint32_t)h, tasks.size() > first ? tasks[first].rp : 0u});

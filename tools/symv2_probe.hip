@@ -97,7 +97,7 @@ pattern_read_kernel(const T *__restrict__ A, const Task *__restrict__ tasks, T *
     using V = typename Vec<T>::t;
     constexpr int VEC = Vec<T>::N, CW = kBlock * VEC, SS = NV * CW;
     Task t = tasks[blockIdx.x];
-    t.nrows &= ~lam::kSymvInterior;
+    t.nrows &= ~lam::kSymvFlags;
     const T *rows = A + (uint64_t)t.row0 * lda + (uint64_t)t.strip * SS;
     T acc = (T)0;
     for (uint32_t b = 0; b + 8 <= t.nrows; b += 8, rows += 8 * lda) {
@@ -237,7 +237,8 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
             const uint32_t run = (uint32_t)(runs.size() / 5), first = (uint32_t)tasks.size();
             for (uint32_t st = 0; st < pl.nstrips; st++) {
                 const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;
-                bool needed, interior = c0 + SS <= n && hgt % 8 == 0;
+                const bool full = c0 + SS <= n && hgt % 8 == 0;
+                bool needed, interior = full;
                 if (!cyc) { needed = c1 >= ga; interior = interior && c0 >= gb; }
                 else {
                     needed = meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2);
@@ -250,7 +251,7 @@ int run(uint64_t n, const std::vector<std::string> &specs, int rounds)
                 }
                 if (!needed) continue;
                 per_strip[st].push_back((uint32_t)tasks.size());
-                tasks.push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u), st, (uint32_t)rp_elems});
+                tasks.push_back({(uint32_t)r, (uint32_t)hgt | (interior ? lam::kSymvInterior : 0u) | (full && !getenv("SYMV2_NO_FULL") ? lam::kSymvFull : 0u), st, (uint32_t)rp_elems});
                 rp_elems += hgt;
             }
             runs.insert(runs.end(), {first, (uint32_t)tasks.size() - first, (uint32_t)r, (uint32_t)hgt, tasks.size() > first ? tasks[first].rp : 0u});
