@@ -475,16 +475,20 @@ def test_reference_generate_grid_known_answers(tmp_path):
     assert sum(x["same_printed_digits"] for x in recs[:-1]) >= 6
 
 
-def test_reference_file_grid_sizes(tmp_path):
-    """The file-mode sizes of TESTS/GPU_SCRIPTS/GPU_1_NODE.sh:41-47 (10000 ... 70000, default tolerance 1e-9) on systems drawn
+@pytest.mark.parametrize("symmetric", [0, 1])
+def test_reference_file_grid_sizes(tmp_path, symmetric):
+    """(symmetric = 1: the same grid with LAM_HIP_SYMMETRIC=1 in the drivers' environment -- the generator's matrices are
+    symmetric bit for bit, every pair is read once, and the reference's published iteration counts must come out all the same.)
+    The file-mode sizes of TESTS/GPU_SCRIPTS/GPU_1_NODE.sh:41-47 (10000 ... 70000, default tolerance 1e-9) on systems drawn
     from the reference GENERATOR's law (round 4: apps/random_spd_system.out and the driver's -R option reproduce it -- spectrum
     exp(3.5 U[-1,1]), rhs U[-1,1], the reference's srand/rand streams): the reference's own runs on its generator's matrices
     took 358-360 iterations at every size (tests/golden/reference_file_grid.json <- TESTS/BEST_RESULTS:93-135), and so must
     these, to 3 % -- the first FILE-mode known answer of the reference the package is held to.  The smallest size goes through
     real files written by the generator tool and the -A/-b loaders."""
     js = tmp_path / "file.json"
+    env = dict(os.environ, LAM_HIP_SYMMETRIC="1") if symmetric else dict(os.environ)
     r = subprocess.run([sys.executable, SWEEP, "--grid", "file", "--json", str(js), "--files", str(tmp_path), "--files-max-n", "10000"],
-                       capture_output=True, text=True, timeout=1500)
+                       capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     import json
     recs = json.load(open(js))
