@@ -165,11 +165,11 @@ struct lam_hip_ctx {
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
 
-    // the symmetric product exists for fp64/fp32 storage (any n): one shard, or several row shards on the gather-Ap exchange
+    // the symmetric product exists for every storage type and any n: one shard, or several row shards on the gather-Ap exchange
     // (inside CG only: every shard contributes a full-length vector per iteration, lam_exchange.h)
     // Option value 1: where it pays -- below N ~ 6000 the two passes' fixed costs outweigh the halved stream (N = 4096: 0.83-0.92 x
     // the general GEMV, N = 10000: 1.44 x; profiles/r04_symmetric_probe.txt); value 2: always (tests of the small sizes).
-    bool symv_wanted() const { return dtype != LAM_HIP_BF16 && n > 0 && (opt_symmetric >= 2 || (opt_symmetric == 1 && n >= 6144)); }
+    bool symv_wanted() const { return n > 0 && (opt_symmetric >= 2 || (opt_symmetric == 1 && n >= 6144)); }
     bool symv_active() const { return symv_wanted() && !rank_mode && total_shards == 1; }
     bool symv_multi_active() const { return symv_wanted() && exchange1_ok(); }
     uint64_t symv_stride_bytes() const { return n * esz_v() + 8; }

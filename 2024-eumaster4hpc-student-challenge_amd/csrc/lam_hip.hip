@@ -958,9 +958,9 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
 int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pairs, uint64_t *bad_interior, uint64_t *ntasks)
 {
     if (n == 0 || shards < 1 || shards > kMaxShards || (uint64_t)shards > n || !bad_pairs || !bad_interior || !ntasks ||
-        (dtype != LAM_HIP_F64 && dtype != LAM_HIP_F32))
+        (dtype != LAM_HIP_F64 && dtype != LAM_HIP_F32 && dtype != LAM_HIP_BF16))
         return LAM_HIP_EINVAL;
-    const uint64_t vec = dtype == LAM_HIP_F64 ? 2 : 4, SS = (uint64_t)kBlock * vec, ncv = (n + vec - 1) / vec * vec;   // NV = 1, as launched
+    const uint64_t vec = dtype == LAM_HIP_F64 ? 2 : (dtype == LAM_HIP_F32 ? 4 : 8), SS = (uint64_t)kBlock * vec, ncv = (n + vec - 1) / vec * vec;   // NV = 1, as launched
     const bool cyc = shards > 1;
     std::vector<uint8_t> count(n * n, 0);                 // count[i * n + j]: how often y_i += A_ij p_j is produced
     auto bump = [&](uint64_t i, uint64_t j) { uint8_t &c = count[i * n + j]; if (c < 255) c++; };

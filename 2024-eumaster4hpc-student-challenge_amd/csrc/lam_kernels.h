@@ -1138,15 +1138,16 @@ constexpr uint32_t kSymvInterior = 0x80000000u;   // flag in SymvTask::nrows (ho
 // CU: the tasks' loads alone run at 7.22 TB/s with three workgroups per CU against 7.0 with the five its registers allow, the
 // whole pass 1-2 % faster (fewer row streams in flight at a time; profiles/r04_symv2_probe.txt).
 constexpr unsigned kSymvLdsPerWorkgroup = 53 * 1024;
-template <typename T> constexpr unsigned symv_lds_pad() { return kSymvLdsPerWorkgroup - (unsigned)sizeof(T) * kWaves * kSymvRowsLds; }
-template <typename T, int NV, bool CYC>
+template <typename T> constexpr unsigned symv_lds_pad() { return kSymvLdsPerWorkgroup - (unsigned)sizeof(T) * kWaves * kSymvRowsLds; }   // T: vector type
+template <typename TA, typename T, int NV, bool CYC>     // TA: storage of the matrix; T: vectors, products, partials (bf16 storage: float)
 __global__ void __launch_bounds__(kBlock)
-symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks, T *__restrict__ rowpart,
+symv_task_kernel(const TA *__restrict__ A, const T *__restrict__ p, const SymvTask *__restrict__ tasks, T *__restrict__ rowpart,
                  T *__restrict__ colpart, uint64_t lda, uint64_t ncols_vec, uint64_t n, uint64_t row_off, const CgScalars *sc)
 {
-    using MV = MatVec<T>;
-    using vec_t = typename MV::vec_t;
+    using MV = MatVec<TA>;
+    using vec_t = typename MV::vec_t;                                // 16 bytes of matrix elements
     constexpr int VEC = MV::N, CW = kBlock * VEC, SS = NV * CW;     // CW: columns the workgroup covers with one vector per lane
+    typedef T tvec_t __attribute__((ext_vector_type(VEC)));          // the same columns of a vector / a column partial
     __shared__ T s_rows[kWaves][kSymvRowsLds];
     if (sc != nullptr && sc->stop) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1156,14 +1157,14 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
     const uint64_t c0 = (uint64_t)t.strip * SS, c = c0 + (uint64_t)tid * VEC;       // this lane's columns: c + v * CW + i
     const uint64_t grow0 = row_off + t.row0;
     bool live[NV];                                                                   // columns behind the row's end: nothing to do
-    vec_t pc[NV];
+    tvec_t pc[NV];
     T cacc[NV][VEC];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         live[v] = c + (uint64_t)v * CW < ncols_vec;
 #pragma unroll
         for (int i = 0; i < VEC; i++) { pc[v][i] = (T)0; cacc[v][i] = (T)0; }
-        if (live[v]) pc[v] = *reinterpret_cast<const vec_t *>(p + c + (uint64_t)v * CW);
+        if (live[v]) pc[v] = *reinterpret_cast<const tvec_t *>(p + c + (uint64_t)v * CW);
     }
     // Interior tasks -- nearly all of them -- take the lean loop: unconditional loads from UNIFORM row bases plus the lane's
     // constant offset (no exec-mask juggling between the loads: the predicated form below issued its loads one branch at a time
@@ -1186,7 +1187,7 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
     };
     auto lean_loop = [&](auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const T *rows = A + (uint64_t)t.row0 * lda + c0;           // uniform
+        const TA *rows = A + (uint64_t)t.row0 * lda + c0;          // uniform
         const T *prow = p + grow0;
         vec_t a0[4][NV], a1[4][NV];
 #pragma unroll
@@ -1210,8 +1211,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                     for (int i = 0; i < VEC; i++) {
                         bool rs = true, cs = true;
                         if (MASKED) symv_use<CYC>(c + (uint64_t)v * CW + i, grow0 + b + k, n, &rs, &cs);
-                        if (rs) r = fma_tv((T)a0[k][v][i], (T)pc[v][i], r);
-                        if (cs) cacc[v][i] = fma_tv((T)a0[k][v][i], pr, cacc[v][i]);
+                        if (rs) r = fma_tv((T)MV::get(a0[k][v], i), (T)pc[v][i], r);
+                        if (cs) cacc[v][i] = fma_tv((T)MV::get(a0[k][v], i), pr, cacc[v][i]);
                     }
                 racc[k] = r;
             }
@@ -1232,8 +1233,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                     for (int i = 0; i < VEC; i++) {
                         bool rs = true, cs = true;
                         if (MASKED) symv_use<CYC>(c + (uint64_t)v * CW + i, grow0 + b + 4 + k, n, &rs, &cs);
-                        if (rs) r = fma_tv((T)a1[k][v][i], (T)pc[v][i], r);
-                        if (cs) cacc[v][i] = fma_tv((T)a1[k][v][i], pr, cacc[v][i]);
+                        if (rs) r = fma_tv((T)MV::get(a1[k][v], i), (T)pc[v][i], r);
+                        if (cs) cacc[v][i] = fma_tv((T)MV::get(a1[k][v], i), pr, cacc[v][i]);
                     }
                 racc[4 + k] = r;
             }
@@ -1253,7 +1254,7 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
     else if (full) lean_loop(std::true_type());      // the rim of the rows' windows in full strips: the same loads, every product tested
     else {
         // ragged strips and row runs: every load and every product tested
-        const T *Arow = A + (uint64_t)t.row0 * lda + c;
+        const TA *Arow = A + (uint64_t)t.row0 * lda + c;
         for (uint32_t b = 0; b < t.nrows; b += 8) {
             vec_t a[8][NV];
             T pr[8];
@@ -1263,7 +1264,7 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
 #pragma unroll
-                    for (int i = 0; i < VEC; i++) a[k][v][i] = (T)0;
+                    for (int i = 0; i < VEC; i++) a[k][v][i] = 0;
                     // one shard: a vector whose columns all lie left of the diagonal is not read at all
                     if (live[v] && b + k < t.nrows && (CYC || c + (uint64_t)v * CW + VEC > grow))
                         a[k][v] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(Arow + (uint64_t)(b + k) * lda + (uint64_t)v * CW));
@@ -1281,8 +1282,8 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
                     for (int i = 0; i < VEC; i++) {
                         bool rs, cs;
                         symv_use<CYC>(c + (uint64_t)v * CW + i, grow, n, &rs, &cs);
-                        if (rs) r = fma_tv((T)a[k][v][i], (T)pc[v][i], r);
-                        if (cs) cacc[v][i] = fma_tv((T)a[k][v][i], pr[k], cacc[v][i]);
+                        if (rs) r = fma_tv((T)MV::get(a[k][v], i), (T)pc[v][i], r);
+                        if (cs) cacc[v][i] = fma_tv((T)MV::get(a[k][v], i), pr[k], cacc[v][i]);
                     }
                 racc[k] = r;
             }
@@ -1294,13 +1295,13 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
 #pragma unroll
     for (int v = 0; v < NV; v++)
         if (live[v]) {
-            vec_t out;
+            tvec_t out;
 #pragma unroll
             for (int i = 0; i < VEC; i++) out[i] = cacc[v][i];
 #ifdef LAM_SYMV_PROBE_NO_PARTIAL_STORES      /* tools/symv2_probe only: what the partial stores cost (results are wrong without them) */
             if (out[0] == (T)123.456)
 #endif
-            __builtin_nontemporal_store(out, reinterpret_cast<vec_t *>(colpart + (uint64_t)blockIdx.x * SS + (uint64_t)v * CW + (uint64_t)tid * VEC));
+            __builtin_nontemporal_store(out, reinterpret_cast<tvec_t *>(colpart + (uint64_t)blockIdx.x * SS + (uint64_t)v * CW + (uint64_t)tid * VEC));
         }
 }
 
@@ -1315,13 +1316,13 @@ symv_task_kernel(const T *__restrict__ A, const T *__restrict__ p, const SymvTas
 // (dst.n > 0): the entry is this shard's CONTRIBUTION to y[i], stored into its record in every shard's gather buffer; the
 // consumer adds the shards' records in shard order; the launch carries one extra workgroup (fin.active) that sums the
 // workgroups' parts of p.Ap in the fixed order of block_sum_array and writes the total behind the record (see Finalize).
-template <typename T, int NV>
+template <typename T, int SS>         // T: vectors and partials; SS: columns of a strip
 __global__ void __launch_bounds__(kBlock)
 symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart, const uint32_t *__restrict__ index, SymvIndex ix,
                    const T *__restrict__ p, T *__restrict__ y, double *__restrict__ partial, uint64_t n, uint64_t row_off,
                    uint64_t nloc, PtrList dst, Finalize fin, const CgScalars *sc)
 {
-    constexpr int SS = NV * kBlock * MatVec<T>::N, RB = kSymvReduceRows, G = kBlock / RB;
+    constexpr int RB = kSymvReduceRows, G = kBlock / RB;
     __shared__ T s[G][RB];
     __shared__ double s_dot[RB];
     __shared__ uint32_t s_list[kSymvListChunk];

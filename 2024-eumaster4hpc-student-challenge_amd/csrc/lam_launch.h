@@ -24,15 +24,15 @@ void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc
     // 4-10 % at N=65536, profiles/r04_symv2_probe.txt), and a task stores SS column partials whatever its height: tall tasks for
     // the bulk, shorter ones only for what is dispatched last (the launch hands out tasks in list order and should end on short
     // ones: the last ~8 % of the work).  One shard (the triangle: row r holds n - r elements): `tall` rows up to the row below
-    // which 60 % of the work lies, tall / 4 up to 92 %, at most 64 after; tall = 2048 from N = 65536 on, N / 64 below; N < 16384:
+    // which 60 % of the work lies, tall / 4 up to 92 %, at most 64 after; tall = the power of two that leaves ~1500 or more tall tasks, at most 2048 (fp64: 2048 from N = 65536 on,
+    // 512 at 32768); N < 16384:
     // two classes, tall up to row 0.65 n and tall / 8 after (a
     // launch wants some thousands of tasks).  Several shards (every row holds n / 2 elements): tall so that a shard has >= ~4000
     // tasks, tall / 4 for its last 8 % of rows.
     uint64_t tall = 32, mid_from, small_from;
     bool two_classes = cyc;
     if (!cyc) {
-        while (tall < 1024 && tall * 64 <= n) tall *= 2;
-        if (n >= 65536) tall = 2048;
+        while (tall < 2048 && 2 * tall * 3000 <= n * nstrips) tall *= 2;     // ~1500 or more tall tasks: n / tall runs x nstrips / 2 strips
         mid_from = (uint64_t)((1.0 - std::sqrt(0.40)) * (double)n);
         small_from = (uint64_t)((1.0 - std::sqrt(0.08)) * (double)n);
         if (n < 16384) {                                           // small systems: the second pass's fixed cost counts, fewer tasks win
@@ -221,13 +221,13 @@ struct Impl {
         DevBuf t, rp, cp, sb;
         HIPCHK(c, hipMalloc(&t.p, tasks.size() * sizeof(SymvTask)));
         if (plan.rowpart_elems >> 32) return fail(c, LAM_HIP_EINVAL, "symmetric product: too many row partials for 32-bit offsets");
-        HIPCHK(c, hipMalloc(&rp.p, (size_t)plan.rowpart_elems * sizeof(TA)));
-        HIPCHK(c, hipMalloc(&cp.p, tasks.size() * SS * sizeof(TA)));
+        HIPCHK(c, hipMalloc(&rp.p, (size_t)plan.rowpart_elems * sizeof(TV)));
+        HIPCHK(c, hipMalloc(&cp.p, tasks.size() * SS * sizeof(TV)));
         HIPCHK(c, hipMalloc(&sb.p, plan.index.size() * sizeof(uint32_t)));
         HIPCHK(c, hipMemcpy(t.p, tasks.data(), tasks.size() * sizeof(SymvTask), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(sb.p, plan.index.data(), plan.index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         // columns behind the end of a ragged strip are never written by a task: the second pass does not read them either
-        HIPCHK(c, hipMemsetAsync(cp.p, 0, tasks.size() * SS * sizeof(TA), s.stream));
+        HIPCHK(c, hipMemsetAsync(cp.p, 0, tasks.size() * SS * sizeof(TV), s.stream));
         s.symv_tasks = t.as<SymvTask>(); s.symv_rowpart = rp.p; s.symv_colpart = cp.p; s.symv_index = sb.as<uint32_t>();
         s.symv_ix = plan.ix;
         t.p = rp.p = cp.p = sb.p = nullptr;
@@ -244,14 +244,14 @@ struct Impl {
         const uint64_t n = c->n, ncv = c->ncols_vec();
         if (s.symv_tasks == nullptr) LAMCHK(build_symv_tasks<NV>(c, s, cyc));
         if (cyc)
-            hipLaunchKernelGGL((symv_task_kernel<TA, NV, true>), dim3(s.symv_ntasks), dim3(kBlock), symv_lds_pad<TA>(), s.stream, (const TA *)s.A, (const TA *)p,
-                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
+            hipLaunchKernelGGL((symv_task_kernel<TA, TV, NV, true>), dim3(s.symv_ntasks), dim3(kBlock), symv_lds_pad<TV>(), s.stream, (const TA *)s.A, p,
+                               (const SymvTask *)s.symv_tasks, (TV *)s.symv_rowpart, (TV *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
         else
-            hipLaunchKernelGGL((symv_task_kernel<TA, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), symv_lds_pad<TA>(), s.stream, (const TA *)s.A, (const TA *)p,
-                               (const SymvTask *)s.symv_tasks, (TA *)s.symv_rowpart, (TA *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
+            hipLaunchKernelGGL((symv_task_kernel<TA, TV, NV, false>), dim3(s.symv_ntasks), dim3(kBlock), symv_lds_pad<TV>(), s.stream, (const TA *)s.A, p,
+                               (const SymvTask *)s.symv_tasks, (TV *)s.symv_rowpart, (TV *)s.symv_colpart, c->lda, ncv, n, s.row0, sc);
         HIPCHK(c, hipGetLastError());
-        hipLaunchKernelGGL((symv_reduce_kernel<TA, NV>), dim3(symv_reduce_grid(n) + (fin.active ? 1 : 0)), dim3(kBlock), 0, s.stream,
-                           (const TA *)s.symv_rowpart, (const TA *)s.symv_colpart, (const uint32_t *)s.symv_index, s.symv_ix, (const TA *)p, (TA *)y,
+        hipLaunchKernelGGL((symv_reduce_kernel<TV, NV * kBlock * VEC>), dim3(symv_reduce_grid(n) + (fin.active ? 1 : 0)), dim3(kBlock), 0, s.stream,
+                           (const TV *)s.symv_rowpart, (const TV *)s.symv_colpart, (const uint32_t *)s.symv_index, s.symv_ix, p, y,
                            partial, n, s.row0, s.nrows, dst, fin, sc);
         HIPCHK(c, hipGetLastError());
         c->n_launch += 2;
@@ -265,17 +265,13 @@ struct Impl {
     static int launch_symv(lam_hip_ctx *c, ShardBase &s, const TV *p, TV *y, double *partial, const CgScalars *sc, const PtrList *dst = nullptr,
                            const Finalize *fin = nullptr)
     {
-        if constexpr (std::is_same<TA, TV>::value) {
-            PtrList none;
-            none.n = 0;
-            const PtrList &d = dst ? *dst : none;
-            Finalize off;
-            off.active = 0; off.mail = 0; off.seq = 0; off.dst.n = 0; off.slot = 0; off.host_err = c->direct_err;
-            const Finalize &f = fin ? *fin : off;
-            return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc, d, f) : launch_symv_nv<1>(c, s, p, y, partial, sc, d, f);
-        } else {
-            return fail(c, LAM_HIP_EINVAL, "the symmetric product needs matrix and vector of one type");
-        }
+        PtrList none;
+        none.n = 0;
+        const PtrList &d = dst ? *dst : none;
+        Finalize off;
+        off.active = 0; off.mail = 0; off.seq = 0; off.dst.n = 0; off.slot = 0; off.host_err = c->direct_err;
+        const Finalize &f = fin ? *fin : off;
+        return symv_nv(c) == 2 ? launch_symv_nv<2>(c, s, p, y, partial, sc, d, f) : launch_symv_nv<1>(c, s, p, y, partial, sc, d, f);
     }
 
     // panel: 0 = whole GEMV; 1 = only columns [lo,hi); 2 = everything but [lo,hi), accumulated onto y

@@ -259,7 +259,7 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   0's stream: it waits for the other shards' posts and records ONE join event they wait for -- 2(P-1)+1
  *                   runtime calls, two event hops on the device; 0 = every stream waits for every other one -- P(P-1) calls,
  *                   one hop.  Same bits.
- *   "symmetric"     fp64/fp32 storage, any N: the matrix-vector product reads every pair {A[i][j], A[j][i]} ONCE (A must equal
+ *   "symmetric"     every storage type, any N: the matrix-vector product reads every pair {A[i][j], A[j][i]} ONCE (A must equal
  *                   its transpose, which CG requires anyway; lam_hip_check_symmetry verifies it) -- half the HBM traffic per
  *                   iteration, 1.7-1.8x the iteration rate at N >= 20000 on one GPU.  One shard: the upper triangle.  Several row
  *                   shards (either multi-GPU topology, on exchange 1, inside CG): every row takes the cyclic window of (N-1)/2

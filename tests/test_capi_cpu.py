@@ -147,15 +147,15 @@ def test_stale_library_is_refused(lam):
     assert "REFUSED" in r.stdout and "rebuild" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 2])
 def test_symmetric_product_plan_covers_every_pair_once(lam, dtype):
     """Host logic of option "symmetric" without a GPU: lam_hip_debug_symv_plan builds the task lists of every shard exactly as the
     launcher does and walks each element through the kernel's own use rule (symv_use, compiled for the host as well).  Every
     directed product y_i += A_ij p_j must come out exactly once -- one shard: the upper triangle; several: cyclic half windows,
     antipodes of even N to the upper half's rows -- and a task flagged interior (processed without any test) may hold no element
-    that the rule would have left out.  Odd and even N, N below / at / above a strip (512 fp64, 1024 fp32 columns), N not a
+    that the rule would have left out.  Odd and even N, N below / at / above a strip (512 fp64, 1024 fp32, 2048 bf16 columns), N not a
     multiple of the vector, shards that do not divide N (the plan itself does not need that; the exchange does)."""
-    sizes = [1, 2, 3, 7, 64, 77, 511, 512, 513, 1000, 1023, 1024, 1025, 1536, 2050, 3000, 4097]
+    sizes = [1, 2, 3, 7, 64, 77, 511, 512, 513, 1000, 1023, 1024, 1025, 1536, 2047, 2048, 2050, 3000, 4097]
     for n in sizes:
         for shards in (1, 2, 3, 4, 5, 8):
             if shards > n:

@@ -3,13 +3,13 @@
 the product alone (lam_hip_gemv_only: launches back to back) and inside CG (cg_iterate).  Bytes: the general product streams
 s*N^2, the symmetric one s*N(N+1)/2; both rates are quoted on their own bytes and against the 8 TB/s HBM peak.
 
-usage: symmetric_probe.py [f64|f32] [N ...]"""
+usage: symmetric_probe.py [f64|f32|bf16] [N ...]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 args = sys.argv[1:]
-dt_name = args.pop(0) if args and args[0] in ("f64", "f32") else "f64"
-dt, esz = (lam.F64, 8) if dt_name == "f64" else (lam.F32, 4)
+dt_name = args.pop(0) if args and args[0] in ("f64", "f32", "bf16") else "f64"
+dt, esz = {"f64": (lam.F64, 8), "f32": (lam.F32, 4), "bf16": (lam.BF16, 2)}[dt_name]
 for n in [int(a) for a in args] or [65536, 40000, 32768, 20000, 10000, 4096]:
     with lam.Solver(dt) as s:
         s.generate_random_spd(n, 1234, 1e6)

@@ -150,12 +150,12 @@ bool pass1(const Plan<T> &pl, const T *A, const T *p, uint64_t n, uint64_t lda, 
 {
     if (g_shard_P > 0) {
         const uint64_t R0 = g_shard_q * (n / g_shard_P);
-        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, R0, (const lam::CgScalars *)nullptr);
-        else hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, R0, (const lam::CgScalars *)nullptr);
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, T, 1, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, R0, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_task_kernel<T, T, 2, true>), dim3(pl.ntasks), dim3(kBlock), 0, g_stream, A + R0 * lda, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, R0, (const lam::CgScalars *)nullptr);
         return true;
     }
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, 1, false>), dim3(pl.ntasks), dim3(kBlock), pl.lds_extra, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, 2, false>), dim3(pl.ntasks), dim3(kBlock), pl.lds_extra, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_task_kernel<T, T, 1, false>), dim3(pl.ntasks), dim3(kBlock), pl.lds_extra, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_task_kernel<T, T, 2, false>), dim3(pl.ntasks), dim3(kBlock), pl.lds_extra, g_stream, A, p, pl.dt, pl.rowpart, pl.colpart, lda, ncols_vec, n, (uint64_t)0, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -169,12 +169,12 @@ bool pass2(const Plan<T> &pl, const T *p, T *y, double *partial, uint64_t n, uin
     nofin.active = 0; nofin.mail = 0; nofin.seq = 0; nofin.dst.n = 0; nofin.slot = 0; nofin.host_err = nullptr;
     if (g_shard_P > 0) {
         const uint64_t nloc = n / g_shard_P, R0 = g_shard_q * nloc;
-        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
-        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
+        if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1 * lam::kBlock * Vec<T>::N>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
+        else hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2 * lam::kBlock * Vec<T>::N>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, R0, nloc, none, nofin, (const lam::CgScalars *)nullptr);
         return true;
     }
-    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
-    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
+    if (pl.NV == 1) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 1 * lam::kBlock * Vec<T>::N>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
+    else if (pl.NV == 2) hipLaunchKernelGGL((lam::symv_reduce_kernel<T, 2 * lam::kBlock * Vec<T>::N>), dim3(grid), dim3(kBlock), 0, g_stream, pl.rowpart, pl.colpart, pl.dsb, pl.ix, p, y, partial, n, (uint64_t)0, n, none, nofin, (const lam::CgScalars *)nullptr);
     else return false;
     return true;
 }
@@ -338,10 +338,10 @@ int main(int argc, char **argv)
     const uint64_t n = strtoull(argv[1], nullptr, 10);
     const bool f32 = !strcmp(argv[2], "f32");
     if (getenv("SYMV2_STREAM")) CHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<double, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<double, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<float, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<float, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<double, double, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<double, double, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<float, float, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)lam::symv_task_kernel<float, float, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pattern_read_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pattern_read_kernel<double, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)pattern_read_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
