@@ -631,6 +631,20 @@ def main():
                     gb = (es4 * float(n4) * n4 + 4.0 * 2 * n4) / 1e9
                     config4.append({"n": n4, "dtype": dname, "path": what4, "kernel": s4.gemv_kernel_name(), "gemv_ms": ts[2] * 1e3,
                                     "gemv_gbps": gb / ts[2], "roofline_frac": gb / ts[2] / HBM_PEAK_GBPS, "algorithmic_bytes": gb * 1e9})
+                # the opt-in symmetric product of the same storage type (every pair read once: half the bytes), priced on ITS bytes
+                try:
+                    s4.set_option("gemv_variant", -1)
+                    s4.set_option("symmetric", 1)
+                    if s4.get_option("symmetric_effective") == 1:
+                        s4.gemv_only(3)
+                        ts = sorted(s4.gemv_only(10) for _ in range(5))
+                        gb = (es4 * float(n4) * (n4 + 1) / 2 + 4.0 * 2 * n4) / 1e9
+                        config4.append({"n": n4, "dtype": dname, "path": "option symmetric (upper-triangle product, two passes; not the GEMV the config names)",
+                                        "kernel": s4.gemv_kernel_name(), "gemv_ms": ts[2] * 1e3, "gemv_gbps": gb / ts[2],
+                                        "roofline_frac": gb / ts[2] / HBM_PEAK_GBPS, "algorithmic_bytes": gb * 1e9})
+                    s4.set_option("symmetric", 0)
+                except Exception as e:   # noqa: BLE001
+                    sys.stderr.write(f"[bench] configs[3] symmetric run ({dname}) failed: {e}\n")
             except Exception as e:   # noqa: BLE001
                 sys.stderr.write(f"[bench] configs[3] run ({dname}) failed: {e}\n")
         if mfma_rows:
