@@ -167,9 +167,13 @@ struct lam_hip_ctx {
 
     // the symmetric product exists for every storage type and any n: one shard, or several row shards on the gather-Ap exchange
     // (inside CG only: every shard contributes a full-length vector per iteration, lam_exchange.h)
-    // Option value 1: where it pays -- below N ~ 6000 the two passes' fixed costs outweigh the halved stream (N = 4096: 0.83-0.92 x
-    // the general GEMV, N = 10000: 1.44 x; profiles/r04_symmetric_probe.txt); value 2: always (tests of the small sizes).
-    bool symv_wanted() const { return n > 0 && (opt_symmetric >= 2 || (opt_symmetric == 1 && n >= 6144)); }
+    // Option value 1: where it pays -- for a matrix below ~200 MB the two passes' fixed costs outweigh the halved stream (fp64: N = 3072
+    // 1.0 x the general GEMV, 4096 1.13-1.18 x, 5120 1.3 x; fp32: 4096 0.8-1.0 x, 8192 1.1 x; bf16: 8192 0.93 x, 16384 1.24 x;
+    // profiles/r04_symmetric_probe.txt): from 192 MiB of matrix on (fp64 N >= 5017, fp32 7095, bf16 10033); value 2: always.
+    bool symv_wanted() const
+    {
+        return n > 0 && (opt_symmetric >= 2 || (opt_symmetric == 1 && n * n * (uint64_t)esz_a() >= (192ull << 20)));
+    }
     bool symv_active() const { return symv_wanted() && !rank_mode && total_shards == 1; }
     bool symv_multi_active() const { return symv_wanted() && exchange1_ok(); }
     uint64_t symv_stride_bytes() const { return n * esz_v() + 8; }

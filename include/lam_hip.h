@@ -264,8 +264,9 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   iteration, 1.7-1.8x the iteration rate at N >= 20000 on one GPU.  One shard: the upper triangle.  Several row
  *                   shards (either multi-GPU topology, on exchange 1, inside CG): every row takes the cyclic window of (N-1)/2
  *                   columns behind its diagonal, so contiguous row shards stay balanced, and each shard contributes a full-length
- *                   vector to the iteration's exchange.  1 = where it pays (N >= 6144; below, the fixed cost of its two passes
- *                   outweighs the halved stream), 2 = at every size, 0 (default) = the reference's general row-partitioned
+ *                   vector to the iteration's exchange.  1 = where it pays (from 192 MiB of matrix on: fp64 N >= 5017, fp32 7095,
+ *                   bf16 10033; below, the fixed cost of its two passes outweighs the halved stream), 2 = at every size, 0
+ *                   (default) = the reference's general row-partitioned
  *                   GEMV.  Same results to rounding (another summation order).  "symmetric_effective" tells whether the current
  *                   context uses it.  Environment LAM_HIP_SYMMETRIC = 1 | 2 sets it for new contexts (drivers).
  *   "finalize"      several shards: 1 (default) = the last workgroup of the GEMV / update kernel reduces the

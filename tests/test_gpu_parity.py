@@ -669,7 +669,7 @@ def test_symmetric_product_matches_general_gemv(lam, dtype_name, n):
         if dtype_name != "BF16":                      # (the symmetry check reads fp64 / fp32 storage; the generator is symmetric bit for bit)
             assert s.check_symmetry() == 0.0
         y0 = s.gemv(x).astype(np.float64)
-        s.set_option("symmetric", 2)                  # 2 = at every size (1 = only where it pays, N >= 6144)
+        s.set_option("symmetric", 2)                  # 2 = at every size (1 = only where it pays: from 192 MiB of matrix on)
         assert s.get_option("symmetric_effective") == 1
         y1 = s.gemv(x).astype(np.float64)
         A = s.download_rows(0, n).astype(np.float64) if n <= 4096 else None
@@ -698,7 +698,7 @@ def test_symmetric_option_preconditions(lam):
     with lam.Solver(lam.F64) as s:
         s.generate_random_spd(4100, 5, 10.0)           # any N (round 1 needed a multiple of 4096) ...
         s.set_option("symmetric", 1)
-        assert s.get_option("symmetric_effective") == 0   # ... but value 1 means "where it pays": N >= 6144
+        assert s.get_option("symmetric_effective") == 0   # ... but value 1 means "where it pays": from 192 MiB of matrix on (fp64: N >= 5017)
         s.generate_random_spd(6150, 5, 10.0)
         assert s.get_option("symmetric_effective") == 1
         s.set_option("symmetric", 2)                      # value 2: at every size

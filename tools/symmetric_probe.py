@@ -18,7 +18,7 @@ for n in [int(a) for a in args] or [65536, 40000, 32768, 20000, 10000, 4096]:
         res = {0: {"gemv": [], "iter": []}, 1: {"gemv": [], "iter": []}}
         for rnd in range(4):
             for sym in (0, 1):
-                s.set_option("symmetric", 2 * sym)      # 2: at every size (1 leaves N < 6144 on the general GEMV)
+                s.set_option("symmetric", 2 * sym)      # 2: at every size (1 leaves matrices below 192 MiB on the general GEMV)
                 assert s.get_option("symmetric_effective") == sym
                 s.gemv_only(3)
                 t = s.gemv_only(reps)
