@@ -1,13 +1,17 @@
-// symv2_probe -- research probe, NOT part of the product: second shape of the upper-triangle product (round 4).
-// The round-1 shape (tools/symv_probe.hip) flushed one column partial per 32 rows: 0.55 GB written + read again per product at
-// N=65536, and its row partials lived in 64 registers per lane.  Here a task is a column STRIP (the 4 KiB the workgroup's 4 waves
-// read contiguously per row: 512 fp64 / 1024 fp32 columns) times a run of rows -- 256 for most of the triangle, 32 for the rows
-// dispatched last, so that the launch ends on short tasks --; a lane keeps its column partials in registers over ALL rows of the
-// task and only 8 row partials at a time, reduced across the wave every 8 rows with a transposed butterfly (10 exchanges for 8
-// rows instead of 48) and parked in LDS until the task ends.  Partials: rowpart[strip][row] + colpart[task][column of the strip]:
-// ~0.1 GB written per product instead of 0.55.  Fixed task list, fixed orders: deterministic.
+// symv2_probe -- research probe, NOT part of the product: drives the PRODUCT's symmetric-product kernels (csrc/lam_kernels.h, included below)
+// with its own task schedules, several plans timed INTERLEAVED in one process (the device's state and the placement of a plan's buffers move
+// this kernel by several percent; only interleaved numbers compare), against a plain full-matrix product on the same data.
+// The round-1 shape (its probe: git history, tools/symv_probe.hip; numbers: profiles/r01_symmetric_option.txt) flushed one column partial per
+// 32 rows (0.55 GB written and read again per product at N=65536) and kept 32 row partials per lane; what this probe found on the way to the
+// current shape is on file in profiles/r04_symv2_probe.txt.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 tools/symv2_probe.hip -o tools/symv2_probe.out ; run: symv2_probe.out [N] [small_from_fraction]
+// usage: symv2_probe.out N f64|f32 rounds SPEC ...        SPEC = [KiB*100+]NV:h1@f1,h2@f2,...,hlast
+//        NV = 16-byte vectors per lane and row (1 | 2), KiB = idle dynamic LDS per workgroup of the first pass (caps the workgroups per CU),
+//        schedule: tasks of h1 rows up to row f1 * N, h2 up to f2 * N, ..., hlast for the rest (heights: multiples of 8, at most 2048)
+// environment: SYMV2_SHARD=q/P  one row shard of a P-way split (cyclic half windows)      SYMV2_READONLY=1  also time the tasks' loads alone
+//              SYMV2_REVERSE=1  time the plans in reverse order      SYMV2_PAD_MB=n  an idle allocation between the matrix and the plans' buffers
+//              SYMV2_GEN=1  a matrix with a large diagonal           SYMV2_STREAM=1  a non-blocking stream        SYMV2_NO_FULL=1  rim tasks on the per-element path
+// build: hipcc --offload-arch=gfx950 -O3 tools/symv2_probe.hip -o tools/symv2_probe.out   (-DLAM_SYMV_PROBE_NO_PARTIAL_STORES: the partial stores compiled out)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
