@@ -4,7 +4,8 @@
 CPU drivers at OMP_NUM_THREADS=1) x every topology the library has --
 
     one shard;  one process with 2 / 3 shards on the three-join event exchange and on the gather-Ap exchange;
-    one process per GPU (rank mode) with 2 / 3 ranks on the stream-ordered RCCL double, exchanges 0 / 1 / 2
+    one process per GPU (rank mode) with 2 / 3 ranks on the stream-ordered RCCL double, exchanges 0 / 1 / 2;
+    and the opt-in symmetric product on one shard and on the gather-Ap exchange of both multi-shard topologies
 
 -- it prints  iters_hip - iters_ref,  ||x - x_ref|| / ||x_ref||,  the residual recomputed with numpy, and at the end the
 largest |iters_hip - iters_ref| (what the iteration gate of the parity tests has to admit; SURVEY 8c proposes max(2, 1 %)).
@@ -47,7 +48,8 @@ def main():
         res = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
         rows.append(f"{g['tag']:28s} ref {g['iters_printed']:4d}  {topo:46s} iters {iters:4d} ({d:+d})  |x-x_ref|/|x_ref| {xe:9.2e}  "
                     f"residual {res:9.2e} (tol {g['tol']:.0e})")
-        worst[topo.split(",")[0]] = max(worst.get(topo.split(",")[0], 0), abs(d))
+        key = topo.split(",")[0] + (" + symmetric" if topo.endswith("symmetric") and "," in topo else "")
+        worst[key] = max(worst.get(key, 0), abs(d))
         return abs(d), xe / g["tol"], res / g["tol"]
 
     stats = []
@@ -60,26 +62,32 @@ def main():
         x_ref = read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
         n = g["n"]
         for shards in (1, 2, 3):
-            for exchange in ((None,) if shards == 1 else (0, 1)):
+            # (exchange, symmetric): the opt-in symmetric product reads every pair {A_ij, A_ji} once -- the fixtures are the reference
+            # generator's Q D Q^T, symmetric to rounding --, on one shard and on the gather-Ap exchange
+            for exchange, sym in (((None, 0), (None, 2)) if shards == 1 else ((0, 0), (1, 0), (1, 2))):
                 if exchange == 1 and n % shards != 0:
                     continue
                 with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
                     assert s.load_matrix_from_file(mpath) and s.load_rhs_from_file(bpath)
                     if exchange is not None:
                         s.set_option("exchange", exchange)
+                    s.set_option("symmetric", sym)
+                    assert s.get_option("symmetric_effective") == (1 if sym else 0)
                     s.solve(g["max_iters"], g["tol"])
                     topo = "one shard" if shards == 1 else f"one process, {shards} shards, {'events x3' if exchange == 0 else 'gather-Ap'}"
+                    if sym:
+                        topo += " + symmetric"
                     stats.append(record(g, topo, s.stats["num_iters"], s.solution(), A, b, x_ref))
         if not have_mock:
             continue
         for P in (2, 3):
-            for exchange in (0, 1, 2):
+            for exchange, sym in ((0, 0), (1, 0), (1, 2), (2, 0)):
                 if exchange == 1 and n % P != 0:
                     continue
                 with tempfile.TemporaryDirectory() as tmp:
                     xf = os.path.join(tmp, "x.npy")
                     env = dict(os.environ, LD_PRELOAD=MOCK, GPU_MAX_HW_QUEUES=str(2 * P + 4), MOCK_RCCL_TIMEOUT_MS="20000")
-                    r = subprocess.run([sys.executable, RUN_RANKS, str(P), str(n), "file", "--matrix", mpath, "--rhs", bpath, "--exchange", str(exchange),
+                    r = subprocess.run([sys.executable, RUN_RANKS, str(P), str(n), "file", "--matrix", mpath, "--rhs", bpath, "--exchange", str(exchange), "--symmetric", str(sym),
                                         "--iters", str(g["max_iters"]), "--tol", repr(g["tol"]), "--no-single", "--save-x", xf],
                                        env=env, capture_output=True, text=True, timeout=300)
                     if r.returncode != 0:
@@ -88,7 +96,7 @@ def main():
                         continue
                     out = json.loads(r.stdout.strip().splitlines()[-1])
                     assert out["ranks_identical"] and out["exchange_effective"] == [exchange] * P, out
-                    stats.append(record(g, f"rank mode (RCCL double), {P} ranks, exchange {exchange}", out["iters"], np.load(xf), A, b, x_ref))
+                    stats.append(record(g, f"rank mode (RCCL double), {P} ranks, exchange {exchange}" + (" + symmetric" if sym else ""), out["iters"], np.load(xf), A, b, x_ref))
     lines = ["# tools/parity_margins.py -- HIP path against the reference's own fixtures (tests/golden), every topology",
              "# columns: fixture, reference iterations, topology, HIP iterations (difference), solution error, residual recomputed with numpy"]
     lines += rows
