@@ -601,6 +601,16 @@ def main():
                 also.append({"n": n_also, "value": args.steps / dt_a, "ms_per_step": ms, "gemv_ms": st_a["t_gemv"] * 1e3,
                              "other_us": (ms - st_a["t_gemv"] * 1e3) * 1e3, "gemv_gbps": gbps, "roofline_frac": gbps / HBM_PEAK_GBPS,
                              "kernel": s.gemv_kernel_name()})
+                try:    # the same system with option symmetric (not the headline's algorithm): iterations/s and the product on its own bytes
+                    st_y, dt_y = run_config(s, n_also, args.warmup, args.steps, barrier, symmetric=True, generate=False)
+                    tri = 8.0 * n_also * (n_also + 1) / 2 + 8.0 * 2 * n_also
+                    also[-1]["symmetric_option"] = {"value": args.steps / dt_y, "product_ms": st_y["t_gemv"] * 1e3,
+                                                    "roofline_frac_on_triangle": tri / st_y["t_gemv"] / 1e9 / HBM_PEAK_GBPS,
+                                                    "speedup": dt_a / dt_y}
+                except Exception as e:   # noqa: BLE001
+                    also[-1]["symmetric_option"] = {"error": str(e)[:200]}
+                finally:
+                    s.set_option("symmetric", 0)
             except Exception as e:   # noqa: BLE001
                 sys.stderr.write(f"[bench] side run N={n_also} failed: {e}\n")
     # BASELINE configs[3]: N=131072 in fp32 and in bf16 storage (fp32 accumulate), GEMV only -- the production VALU
