@@ -526,6 +526,8 @@ def main():
                 want = opts.get("exchange")
                 if want is not None and s.get_option("exchange_effective") != want:
                     raise RuntimeError(f"exchange {want} is not available for this configuration (N % shards, shared devices, peer mappings)")
+                if opts.get("symmetric") and s.get_option("symmetric_effective") != 1:
+                    raise RuntimeError("option symmetric is not effective for this configuration")
                 if args.warmup > 0:
                     s.cg_iterate(args.warmup, 0.0)
                 h0_ = s.get_option("host_enqueue_ns")
