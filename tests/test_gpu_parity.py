@@ -628,6 +628,39 @@ def test_randomised_sizes_and_shards(lam, oracle):
         assert np.linalg.norm(x - x_ref) <= tol * np.linalg.norm(x_ref), (case, n, P, dt_name, k)
 
 
+def test_randomised_sizes_and_shards_symmetric(lam, oracle):
+    """The same drill with option symmetric = 2: random sizes (rows shorter than a vector, than a strip; odd and even N -- the
+    antipode rule --; ragged last strips and last tasks), 1 ... 6 row shards (N a multiple of the shard count: the gather-Ap
+    exchange), every storage type; a few iterations against the fp64 oracle on the matrix the device holds."""
+    rng = np.random.default_rng(4202)
+    for case in range(40):
+        P = int(rng.integers(1, 7))
+        n = P * int(rng.integers(1, 1500 // P + 1))
+        dt_name = ["F64", "F64", "F32", "BF16"][int(rng.integers(0, 4))]
+        q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
+        A = (q * np.exp(1.5 * rng.uniform(-1, 1, n))) @ q.T
+        A = 0.5 * (A + A.T)                              # symmetric bit for bit (a + b == b + a), in every storage type
+        b = rng.uniform(-1, 1, n)
+        k = int(rng.integers(1, 12))
+        with lam.Solver(getattr(lam, dt_name), n_shards=P, device_ids=[0] * P) as s:
+            s.set_matrix(A)
+            s.set_rhs(b)
+            s.set_option("symmetric", 2)
+            # several shards: the gather-Ap exchange wants the slice's bytes a multiple of 8 (fp32 vectors: an even slice); else the
+            # context stays on the sliced-vector exchange and on the general GEMV
+            expect = 1 if P == 1 or ((n // P) * (8 if dt_name == "F64" else 4)) % 8 == 0 else 0
+            assert s.get_option("symmetric_effective") == expect, (case, n, P, dt_name)
+            A_dev = s.download_rows(0, n).astype(np.float64)
+            assert np.array_equal(A_dev, A_dev.T)
+            s.solve(k, 1e-30)
+            x, st = s.solution().astype(np.float64), s.stats
+        x_ref, st_ref = oracle.cg_solve(A_dev, b, k, 1e-30)
+        assert st["num_iters"] == st_ref["num_iters"] == k + 1
+        tol = 1e-9 if dt_name == "F64" else 2e-3
+        assert abs(st["rel_err"] / st_ref["rel_err"] - 1) < tol, (case, n, P, dt_name, k)
+        assert np.linalg.norm(x - x_ref) <= tol * np.linalg.norm(x_ref), (case, n, P, dt_name, k)
+
+
 def test_maximum_size_known_answer(lam):
     """Edge case 'maximum sizes': N=180000 fp64 = 259 GB, 90 % of the 288 GB HBM3E of one MI355X (the
     reference needed 8+ GPUs' worth of nodes for its N=180000 generate-mode runs,
