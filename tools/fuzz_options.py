@@ -27,7 +27,7 @@ def run(dt, n, shards, seed, opts, chunks):
         st = None
         for c in chunks:
             st = s.cg_iterate(c, 0.0)
-        eff = {k: s.get_option(k) for k in ("fuse_effective", "persistent_effective", "exchange_effective")}
+        eff = {k: s.get_option(k) for k in ("fuse_effective", "persistent_effective", "exchange_effective", "symmetric_effective")}
         return s.solution(), st["rel_err"], st["num_iters"], eff, s.true_residual()
 
 
@@ -49,17 +49,21 @@ def main():
         # the exchange is part of the CASE (gather-Ap sums r.r over full-length partials: other bits than the sliced form)
         exchange = rng.choice((0, 1)) if shards > 1 else 0
         base = {"exchange": exchange} if shards > 1 else {}
+        # the symmetric product is part of the CASE too (another summation order): one case in three runs on it (one shard: the
+        # upper triangle; several on the gather-Ap exchange: cyclic half windows; elsewhere the option has no effect)
+        if rng.random() < 0.34:
+            base["symmetric"] = 2
         ref = run(dt, n, shards, seed, base, [total])
         opts = dict(base, fuse_update=rng.choice((0, 1)), gemv_timing=rng.choice((0, 1, 3, 8)), exchange_join=rng.choice((0, 1)))
         if TUNING:
             opts.update({"finalize": rng.choice((1, 1, 0)), "host_threads": rng.choice((0, 1)), "exchange_hub": rng.choice((0, 1)),
-                         "persistent": rng.choice((0, 1)), "persist_chunk": rng.choice((1, 2, 7, 32))})
-            if opts["persistent"]:
+                         "persistent": 0 if base.get("symmetric") else rng.choice((0, 1)), "persist_chunk": rng.choice((1, 2, 7, 32))})
+            if opts["persistent"] and not base.get("symmetric"):
                 # the persistent launch shares the tile body of GEMV shape 10 (fp64's default is 13): same shape on both sides
                 base = dict(base, gemv_variant=10)
                 opts["gemv_variant"] = 10
                 ref = run(dt, n, shards, seed, base, [total])
-        if direct and shards > 1 and exchange == 0:
+        if direct and shards > 1 and exchange == 0 and not base.get("symmetric"):
             # the in-kernel flag exchange between the local shards, one GEMV launch per shard (the own-slice panel of
             # overlap = 1 adds a row's products in another order): same bits as the event exchange; needs finalize = 1
             opts.update({"exchange": 2, "overlap": 0, "finalize": 1})
