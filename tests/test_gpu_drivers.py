@@ -236,18 +236,22 @@ def test_mpi_bootstrapped_driver_multi_rank(tmp_path, mock_mp_lib, mock_async, n
         assert len(lines) == nranks and all(l["abort"] == 0 for l in lines) and len({l["calls"] for l in lines}) == 1, lines
 
 
-@pytest.mark.parametrize("exchange", ["1", "2"])
+@pytest.mark.parametrize("exchange", ["1", "2", "1+symmetric"])
 def test_mpi_driver_other_exchanges_across_processes(tmp_path, mock_async, exchange):
     """LAM_HIP_EXCHANGE=1 (one all-gather per iteration) and =2 (direct: p replicas and mailboxes of the other
     PROCESSES mapped through HIP IPC, no collective inside the iteration) under `mpiexec -n 4`, run to
-    convergence; set-up collectives go through the stream-ordered test double."""
+    convergence; set-up collectives go through the stream-ordered test double.  "1+symmetric": exchange 1 with
+    LAM_HIP_SYMMETRIC=2 -- the symmetric product on row shards across four processes (each gathers the others' full-length
+    contributions), the reference's 2048-iteration known answer of the tridiagonal system all the same."""
     import json
     exe = os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP_RCCL_mpi.out")
     mpiexec = "/opt/conda/bin/mpiexec"
     if not (os.path.exists(exe) and os.path.exists(mpiexec)):
         pytest.skip("MPI driver not built (make mpi)")
     env = {"LD_PRELOAD": mock_async, "GPU_MAX_HW_QUEUES": "8", "MOCK_RCCL_STATS_FILE": str(tmp_path / "st.jsonl"),
-           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LAM_HIP_EXCHANGE": exchange, "LAM_HIP_EXPERIMENTAL_DIRECT": "1"}
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LAM_HIP_EXCHANGE": exchange[0], "LAM_HIP_EXPERIMENTAL_DIRECT": "1"}
+    if exchange.endswith("symmetric"):
+        env["LAM_HIP_SYMMETRIC"] = "2"
     genv = []
     for k, v in env.items():
         genv += ["-genv", k, v]
