@@ -836,6 +836,23 @@ def test_fused_update_needs_a_fully_resident_grid(lam, dtype_name, n):
     assert res[0][1:] == res[1][1:]
 
 
+@pytest.mark.parametrize("shards,n", [(2, 4096), (3, 3000), (8, 8192)])
+def test_fused_full_update_needs_a_fully_resident_grid(lam, shards, n):
+    """The gather-Ap exchange's fused vector step (update_full_fused_kernel) has the same constraint, per device: the launches of
+    ALL shards that share a device must be resident together (here every shard is on GPU 0).  Pretending the device has one CU
+    selects the two-kernel form -- with the same bits."""
+    res = []
+    for cus in (0, 1):
+        with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
+            s.generate_random_spd(n, 5, 300.0)
+            s.generate_random_rhs(6)
+            s.set_option("assume_cus", cus)
+            s.solve(400, 1e-9)
+            assert s.get_option("exchange_effective") == 1
+            res.append((s.get_option("fuse_effective"), s.stats["num_iters"], s.stats["rel_err"], s.solution().tobytes()))
+    assert res[0][0] == 1 and res[1][0] == 0 and res[0][1:] == res[1][1:]
+
+
 @pytest.mark.parametrize("shards,n", [(2, 1024), (3, 3000), (8, 4096), (5, 1001)])
 def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
     """The three-join event exchange ordered by all-to-all stream waits (product), through a hub stream, and with one enqueue
