@@ -164,6 +164,12 @@ struct lam_hip_ctx {
     int *direct_err = nullptr;                  // pinned host: a bounded in-kernel wait expired ([0] = which, see cg_iterate)
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
+    int ranks_on_device = 1;       // rank mode: ranks of the communicator that share THIS rank's GPU (emulations; counted once at
+                                   // creation over the communicator): their fused vector-step launches must all be resident together
+    bool symmetric_from_env = false;   // option "symmetric" came from LAM_HIP_SYMMETRIC (a driver that cannot call set_option): the
+                                       // library then verifies A = A^T itself where it can and says when the option is not effective
+    uint64_t matrix_gen = 0, sym_checked_gen = ~0ull;   // the matrix contents changed / were last checked for symmetry
+    bool sym_refused = false;      // the environment asked for the symmetric product and the matrix is not symmetric: general GEMV
 
     // the symmetric product exists for every storage type and any n: one shard, or several row shards on the gather-Ap exchange
     // (inside CG only: every shard contributes a full-length vector per iteration, lam_exchange.h)
@@ -172,21 +178,22 @@ struct lam_hip_ctx {
     // profiles/r04_symmetric_probe.txt): from 192 MiB of matrix on (fp64 N >= 5017, fp32 7095, bf16 10033); value 2: always.
     bool symv_wanted() const
     {
-        return n > 0 && (opt_symmetric >= 2 || (opt_symmetric == 1 && n * n * (uint64_t)esz_a() >= (192ull << 20)));
+        return n > 0 && !sym_refused && (opt_symmetric >= 2 || (opt_symmetric == 1 && n * n * (uint64_t)esz_a() >= (192ull << 20)));
     }
     bool symv_active() const { return symv_wanted() && !rank_mode && total_shards == 1; }
     bool symv_multi_active() const { return symv_wanted() && exchange1_ok(); }
-    uint64_t symv_stride_bytes() const { return n * esz_v() + 8; }
+    // a shard's record in the symmetric product's gather: its full-length contribution, then (8-byte aligned) its part of p.Ap
+    uint64_t symv_stride_bytes() const { return (n * esz_v() + 7) / 8 * 8 + 8; }
 
     bool exchange2_wanted() const { return (rank_mode || total_shards > 1) && opt_exchange == 2 && opt_finalize != 0; }
-    // gather-Ap needs equal slices and an 8-byte aligned tail for the double (total_shards == nranks in rank mode)
-    bool exchange1_ok() const
-    {
-        return (rank_mode || total_shards > 1) && opt_exchange == 1 && n % (uint64_t)total_shards == 0 &&
-               ((n / (uint64_t)total_shards) * esz_v()) % 8 == 0;
-    }
+    // gather-Ap serves the reference's partition as it is (ConjugateGradient_CPU_MPI_OMP.hpp:176-196: n / P rows each, the
+    // remainder on the LAST shard, gathered there with MPI_Allgatherv + sendcounts / displs, :505): every record has room for the
+    // LONGEST slice (n / P + n % P rows; the shorter ones leave the rest unused -- one equal-count ncclAllGather in rank mode),
+    // followed by the shard's part of p.Ap as a double on an 8-byte boundary.  Any n >= P.
+    bool exchange1_ok() const { return (rank_mode || total_shards > 1) && opt_exchange == 1 && n >= (uint64_t)total_shards; }
     uint64_t ex1_base() const { return n / (uint64_t)total_shards; }
-    uint64_t ex1_stride_bytes() const { return ex1_base() * esz_v() + 8; }
+    uint64_t ex1_maxrows() const { return n / (uint64_t)total_shards + n % (uint64_t)total_shards; }
+    uint64_t ex1_stride_bytes() const { return (ex1_maxrows() * esz_v() + 7) / 8 * 8 + 8; }
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
     static uint64_t pitch_for(uint64_t n, size_t ea)
@@ -252,6 +259,15 @@ int fail(lam_hip_ctx *c, int code, const char *fmt, ...)
         (c)->n_wait++;                               \
         HIPCHK((c), hipStreamWaitEvent((st), (ev), 0)); \
     } while (0)
+
+// the matrix contents changed (upload, generators): the CG state and what was known about the old contents are void
+void matrix_changed(lam_hip_ctx *c)
+{
+    c->have_matrix = true;
+    c->cg_ready = false;
+    c->matrix_gen++;
+    c->sym_refused = false;
+}
 
 void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
 {

@@ -35,9 +35,78 @@ int64_t symmetric_from_env(int64_t dflt)
     return (k >= 0 && k <= 2) ? k : dflt;
 }
 
+// max |A - A^T| and max |A| of a single-shard context's matrix (one tiled pass over the upper triangle and its mirror image)
+int measure_asymmetry(lam_hip_ctx *c, double *max_asym, double *max_abs)
+{
+    return dispatch(c, [&](auto impl) -> int {
+        using TA = typename ImplTraits<decltype(impl)>::TA;
+        ShardBase &s = c->sh[0];
+        LAMCHK(set_dev(c, s));
+        const int grid = 2048;
+        DevBuf outb;
+        HIPCHK(c, hipMalloc(&outb.p, sizeof(double) * 2 * grid));
+        std::vector<double> h(2 * grid);
+        hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->lda, c->n, outb.as<double>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(h.data(), outb.p, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+        double m = 0.0, a = 0.0;
+        for (int i = 0; i < grid; i++) { m = std::max(m, h[i]); a = std::max(a, h[grid + i]); }
+        *max_asym = m;
+        *max_abs = a;
+        return 0;
+    });
+}
+
+// Option "symmetric" asked for through the ENVIRONMENT (a driver that cannot call lam_hip_set_option or lam_hip_check_symmetry,
+// e.g. the reference's own driver sources compiled against these headers): the library vouches for the precondition itself.
+//   * not effective (rank mode / several shards on an exchange other than gather-Ap): said once on stderr, the general GEMV runs;
+//   * one shard: A is compared with its transpose once per matrix (one pass over A).  Equal bit for bit: nothing to say.
+//     Unequal at rounding level (<= 64 ulp of the largest element: a file written by a generator that rounds A_ij and A_ji
+//     separately, like the reference's MKL-based one): a warning -- the upper triangle then DEFINES the system that is solved.
+//     More: refused, the general GEMV runs (and says so);
+//   * several shards: the transpose lives on other devices -- not checked, the caller vouches as with the option.
+int env_symmetric_check(lam_hip_ctx *c)
+{
+    if (!c->symmetric_from_env || c->opt_symmetric == 0) return 0;
+    static std::atomic<bool> told_ineffective{false};
+    if (c->symv_wanted() && !c->symv_active() && !c->symv_multi_active()) {
+        if (!told_ineffective.exchange(true) && c->rank == 0)
+            fprintf(stderr, "lam_hip: LAM_HIP_SYMMETRIC=%lld is not effective here: with several shards / ranks the symmetric product runs on "
+                            "the gather-Ap exchange only (exchange is %lld; set LAM_HIP_EXCHANGE=1) -- using the general GEMV\n",
+                    (long long)c->opt_symmetric, (long long)c->opt_exchange);
+        return 0;
+    }
+    if (!c->symv_active() || c->sym_checked_gen == c->matrix_gen) return 0;
+    double asym = 0.0, amax = 0.0;
+    LAMCHK(measure_asymmetry(c, &asym, &amax));
+    c->sym_checked_gen = c->matrix_gen;
+    const double eps = c->dtype == LAM_HIP_F64 ? 2.220446049250313e-16 : (c->dtype == LAM_HIP_F32 ? 1.1920929e-07 : 7.8125e-03);
+    if (asym == 0.0) return 0;
+    if (asym <= 64.0 * eps * amax) {
+        fprintf(stderr, "lam_hip: LAM_HIP_SYMMETRIC: max|A - A^T| = %.3e (max|A| = %.3e): equal to rounding only -- the upper triangle "
+                        "defines the system that is solved\n", asym, amax);
+        return 0;
+    }
+    fprintf(stderr, "lam_hip: LAM_HIP_SYMMETRIC refused: the matrix is not symmetric (max|A - A^T| = %.3e, max|A| = %.3e) -- using the "
+                    "general GEMV\n", asym, amax);
+    c->sym_refused = true;
+    for (auto &s : c->sh)
+        s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
+    return 0;
+}
+
 int create_common(lam_hip_ctx *c)
 {
-    c->opt_symmetric = symmetric_from_env(c->opt_symmetric);
+    {
+        const int64_t before = c->opt_symmetric;
+        c->opt_symmetric = symmetric_from_env(c->opt_symmetric);
+        c->symmetric_from_env = c->opt_symmetric != before || (getenv("LAM_HIP_SYMMETRIC") != nullptr && c->opt_symmetric != 0);
+        // rank mode runs the symmetric product on the gather-Ap exchange only: a driver that asks for one through the environment
+        // gets the other with it, unless it chose an exchange itself
+        const char *ex = getenv("LAM_HIP_EXCHANGE");
+        if (c->symmetric_from_env && c->rank_mode && (ex == nullptr || *ex == '\0')) c->opt_exchange = 1;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -91,6 +160,36 @@ int create_common(lam_hip_ctx *c)
                     return fail(nullptr, LAM_HIP_EHIP, "hipDeviceEnablePeerAccess(%d->%d): %s", s.dev, t.dev, hipGetErrorString(pe));
                 (void)hipGetLastError();
             }
+    return 0;
+}
+
+// Rank mode, once per context (collective: part of lam_hip_create_rank): how many ranks of the communicator sit on THIS rank's
+// GPU?  One per device in production; emulations and the MPI driver's `local_rank % device count` mapping put several there, and
+// launches whose workgroups wait for each other (the fused vector steps) must then be resident for all of them together.  The ranks
+// all-gather {host id, PCI bus id of the device} through the set-up scratch.
+int count_ranks_on_device(lam_hip_ctx *c)
+{
+    c->ranks_on_device = 1;
+    if (!c->rank_mode || c->nranks <= 1) return 0;
+    ShardBase &s = c->sh[0];
+    LAMCHK(set_dev(c, s));
+    constexpr size_t kRec = 128;
+    static_assert(kRec * kMaxShards <= 4096, "device records fit the set-up scratch");
+    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, 4096));
+    std::vector<char> host(kRec * (size_t)c->nranks, 0);
+    char *mine = host.data() + kRec * (size_t)c->rank;
+    (void)gethostname(mine, 63);
+    mine[63] = '\0';
+    if (hipDeviceGetPCIBusId(mine + 64, 63, s.dev) != hipSuccess) { (void)hipGetLastError(); snprintf(mine + 64, 63, "device %d", s.dev); }
+    char *dev = (char *)c->agree_buf;
+    HIPCHK(c, hipMemcpyAsync(dev + kRec * (size_t)c->rank, mine, kRec, hipMemcpyHostToDevice, s.stream));
+    NCCLCHK(c, ncclAllGather(dev + kRec * (size_t)c->rank, dev, kRec, ncclChar, c->comm, s.stream));
+    c->n_collectives++;
+    HIPCHK(c, hipMemcpyAsync(host.data(), dev, kRec * (size_t)c->nranks, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(c, hipStreamSynchronize(s.stream));
+    int same = 0;
+    for (int q = 0; q < c->nranks; q++) same += memcmp(host.data() + kRec * (size_t)q, mine, kRec) == 0 ? 1 : 0;
+    c->ranks_on_device = std::max(1, same);
     return 0;
 }
 
@@ -316,11 +415,7 @@ int gather_p_step(lam_hip_ctx *c)
 
 }  // namespace
 
-// The typed bodies below are written as generic lambdas over Impl<TA,TV>; TV is recovered with
-// this small trait.
 namespace {
-template <typename T> struct ImplTraits;
-template <typename TA_, typename TV_> struct ImplTraits<Impl<TA_, TV_>> { using TA = TA_; using TV = TV_; };
 
 // Fill the partial arrays with the sentinel the reducer workgroups wait on (lam_kernels.h, Finalize).
 // Enqueued at the end of cg_init: whatever wrote plain values into them before (cg_init's own partials,
@@ -533,8 +628,10 @@ template <typename TV>
 bool full_fused_launch_resident(lam_hip_ctx *c)
 {
     for (const auto &s : c->sh) {
-        int sharing = 0;
-        for (const auto &t : c->sh) sharing += t.dev == s.dev ? 1 : 0;
+        // one process: the shards of this context on the same device; rank mode: the ranks of the communicator on this rank's
+        // device (count_ranks_on_device, at creation) -- 8 ranks x 257 workgroups would not fit the 2048 slots of one MI355X
+        int sharing = c->rank_mode ? c->ranks_on_device : 0;
+        if (!c->rank_mode) for (const auto &t : c->sh) sharing += t.dev == s.dev ? 1 : 0;
         if (!launch_resident(c, s, update_full_fused_kernel<TV>, sharing * (vec_grid(c->n) + 1))) return false;
     }
     return true;
@@ -759,7 +856,7 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
             PtrList yp;
             yp.n = 0;
             for (auto &t : c->sh) {
-                f.dst.p[t.index] = buf(t) + off + base * sizeof(TV);
+                f.dst.p[t.index] = buf(t) + off + stride - 8;
                 if (&t != &s) yp.p[yp.n++] = buf(t) + off;
             }
             const bool timed = timed_iteration(c, s, k);
@@ -822,8 +919,24 @@ int do_cg_init_exchange1(lam_hip_ctx *c)
         ShardBase &s = c->sh[0];
         LAMCHK(set_dev(c, s));
         const ncclDataType_t dt = c->dtype == LAM_HIP_F64 ? ncclDouble : ncclFloat;
-        NCCLCHK(c, ncclAllGather(s.b, s.r_full, c->ex1_base(), dt, c->comm, s.stream));   // r_full = b
-        c->n_collectives++;
+        // r_full = b.  Equal slices: one all-gather; the reference's uneven partition (remainder on the last rank, gathered
+        // there with MPI_Allgatherv): one grouped broadcast per owner, as for p on exchange 0
+        if (c->n % (uint64_t)c->nranks == 0) {
+            NCCLCHK(c, ncclAllGather(s.b, s.r_full, c->ex1_base(), dt, c->comm, s.stream));
+            c->n_collectives++;
+        } else {
+            const size_t ev = c->esz_v();
+            HIPCHK(c, hipMemcpyAsync((char *)s.r_full + s.row0 * ev, s.b, s.nrows * ev, hipMemcpyDeviceToDevice, s.stream));
+            NCCLCHK(c, ncclGroupStart());
+            for (int q = 0; q < c->nranks; q++) {
+                uint64_t r0, nr;
+                partition(c->n, c->nranks, q, &r0, &nr);
+                char *ptr = (char *)s.r_full + r0 * ev;
+                NCCLCHK(c, ncclBroadcast(ptr, ptr, nr, dt, q, c->comm, s.stream));
+                c->n_collectives++;
+            }
+            NCCLCHK(c, ncclGroupEnd());
+        }
         const int grid = vec_grid(c->n);
         hipLaunchKernelGGL((cg_init_full_kernel<TV>), dim3(grid), dim3(kBlock), 0, s.stream, (TV *)s.r_full, (TV *)s.p,
                            (TV *)s.x, c->n, s.nrows, s.part_vec);
@@ -855,7 +968,7 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
         //    behind the slice (with option "finalize" = 0: a 1-block launch does)
         Finalize f = no_finalize(c);
         f.active = c->opt_finalize ? 1 : 0;
-        f.dst.n = 1; f.dst.p[0] = rec + base * sizeof(TV); f.slot = 0;
+        f.dst.n = 1; f.dst.p[0] = rec + stride - 8; f.slot = 0;
         const bool timed = timed_iteration(c, s, k);
         s.split_slot[slot] = false;
         s.timed_slot[slot] = timed;

@@ -163,6 +163,14 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
             return fail(nullptr, LAM_HIP_ERCCL, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, ncclGetErrorString(r));
         }
         c->t_comm_init = now_s() - t0;
+        rc = count_ranks_on_device(c.get());
+        if (rc != 0) {
+            g_create_error = c->err;
+            (void)ncclCommDestroy(c->comm);
+            c->comm = nullptr;
+            abandon(c.get());
+            return rc;
+        }
     }
     *out = c.release();
     return 0;
@@ -241,7 +249,7 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         if (c->rank_mode || c->total_shards > 1) {
             // gather-Ap exchange (option exchange = 1): full-length r, and the records [Ap slice | p.Ap partial] of all shards
             HIPCHK(c, hipMalloc(&s.r_full, n * ev + 16));
-            s.ap_gather_bytes = ((size_t)c->total_shards * ((n / (uint64_t)c->total_shards + 1) * ev + 8) + 16 + 255) / 256 * 256;
+            s.ap_gather_bytes = ((size_t)c->total_shards * c->ex1_stride_bytes() + 16 + 255) / 256 * 256;
             HIPCHK(c, hipMalloc(&s.ap_gather, s.ap_gather_bytes * (c->rank_mode ? 1 : 2)));
         }
         HIPCHK(c, hipMalloc((void **)&s.sc, sizeof(CgScalars)));
@@ -369,7 +377,7 @@ static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, 
     }
     if (covered != nrows)
         return fail(c, LAM_HIP_EINVAL, "rows [%llu,+%llu) are not all owned by this process", (unsigned long long)row0, (unsigned long long)nrows);
-    if (upload) { c->have_matrix = true; c->cg_ready = false; }
+    if (upload) matrix_changed(c);
     return 0;
 }
 
@@ -397,7 +405,7 @@ int lam_hip_generate_tridiag(lam_hip_ctx *c)
         return 0;
     }));
     LAMCHK(sync_all(c));
-    c->have_matrix = true; c->cg_ready = false;
+    matrix_changed(c);
     return 0;
 }
 
@@ -417,7 +425,7 @@ int lam_hip_generate_random_spd(lam_hip_ctx *c, uint64_t seed, double cond)
         return 0;
     }));
     LAMCHK(sync_all(c));
-    c->have_matrix = true; c->cg_ready = false;
+    matrix_changed(c);
     return 0;
 }
 
@@ -462,7 +470,7 @@ int lam_hip_generate_spectrum_spd(lam_hip_ctx *c, const double *eig, const doubl
         return 0;
     }));
     LAMCHK(sync_all(c));
-    c->have_matrix = true; c->cg_ready = false;
+    matrix_changed(c);
     // 1. one two-sided reflection per vector
     for (int j = 0; j < k; j++) {
         const double *vj = v + (size_t)j * n;
@@ -493,7 +501,7 @@ int lam_hip_generate_spectrum_spd(lam_hip_ctx *c, const double *eig, const doubl
         }));
         LAMCHK(sync_all(c));
     }
-    c->have_matrix = true; c->cg_ready = false;
+    matrix_changed(c);
     return 0;
 }
 
@@ -930,29 +938,8 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
     if (!c || !max_abs_asymmetry) return LAM_HIP_EINVAL;
     if (!c->have_matrix) return fail(c, LAM_HIP_ESTATE, "matrix not set");
     if (c->rank_mode || c->total_shards != 1) return fail(c, LAM_HIP_EINVAL, "symmetry check needs the whole matrix on one shard");
-    return dispatch(c, [&](auto impl) -> int {
-        using TA = typename ImplTraits<decltype(impl)>::TA;
-        ShardBase &s = c->sh[0];
-        LAMCHK(set_dev(c, s));
-        const int grid = 2048;
-        DevBuf outb;
-        HIPCHK(c, hipMalloc(&outb.p, sizeof(double) * grid));
-        double *out = outb.as<double>();
-        std::vector<double> h(grid);
-        if constexpr (sizeof(TA) == 2) {
-            return fail(c, LAM_HIP_EINVAL, "symmetry check is implemented for fp64/fp32 storage");
-        } else {
-            hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->lda, c->n, out);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(h.data(), out, sizeof(double) * grid, hipMemcpyDeviceToHost, s.stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-            if (e != hipSuccess) return fail(c, LAM_HIP_EHIP, "symmetry check: %s", hipGetErrorString(e));
-            double m = 0.0;
-            for (double v : h) m = std::max(m, v);
-            *max_abs_asymmetry = m;
-            return 0;
-        }
-    });
+    double max_abs = 0.0;
+    return measure_asymmetry(c, max_abs_asymmetry, &max_abs);
 }
 
 int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pairs, uint64_t *bad_interior, uint64_t *ntasks)

@@ -99,6 +99,7 @@ int do_cg_init(lam_hip_ctx *c)
     c->seq_span = 1;
     for (auto &sh_ : c->sh) sh_.waited_k = 0;
     if (c->direct_err) memset(c->direct_err, 0, 64);
+    LAMCHK(env_symmetric_check(c));
     if (c->exchange2_wanted()) {
         // the state is initialised through RCCL (one-off); the iterations then run on the mailboxes
         LAMCHK(setup_direct(c));

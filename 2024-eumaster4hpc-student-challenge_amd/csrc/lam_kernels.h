@@ -1393,29 +1393,57 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
     }
 }
 
-// max |A[i][j] - A[j][i]| over the local matrix (single shard), per-workgroup maxima in out[]
+// max |A[i][j] - A[j][i]| over the local matrix (single shard) and max |A[i][j]| over the same elements: per-workgroup maxima in
+// out[blockIdx.x] and out[gridDim.x + blockIdx.x].  32 x 32 tiles of the upper triangle through LDS, so that both the tile and its
+// mirror image are read along rows (one pass over the matrix at a useful fraction of the stream rate: this runs once per matrix when
+// a driver asks for the symmetric product through the environment, lam_exchange.h env_symmetric_check).
+__device__ __forceinline__ double elem_as_double(double v) { return v; }
+__device__ __forceinline__ double elem_as_double(float v) { return (double)v; }
+__device__ __forceinline__ double elem_as_double(__hip_bfloat16 v) { return (double)__uint_as_float(((unsigned)*reinterpret_cast<const unsigned short *>(&v)) << 16); }
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 asymmetry_kernel(const T *__restrict__ A, uint64_t lda, uint64_t n, double *__restrict__ out)
 {
-    __shared__ double s_max[kWaves];
-    double m = 0.0;
-    const uint64_t total = n * n;
-    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * kBlock) {
-        const uint64_t i = idx / n, j = idx % n;
-        if (j > i) {
-            const double d = fabs((double)A[i * lda + j] - (double)A[j * lda + i]);
+    constexpr int TS = 32;
+    __shared__ double s_up[TS][TS + 1], s_lo[TS][TS + 1];
+    __shared__ double s_max[2][kWaves];
+    double m = 0.0, a = 0.0;
+    const uint64_t nt = (n + TS - 1) / TS, ntiles = nt * (nt + 1) / 2;
+    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;          // 32 x 8 threads: four row passes per tile
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // tile (bi, bj) with bj >= bi, numbered row by row of the upper block triangle
+        uint64_t bi = (uint64_t)((2.0 * (double)nt + 1.0 - sqrt((2.0 * (double)nt + 1.0) * (2.0 * (double)nt + 1.0) - 8.0 * (double)t)) * 0.5);
+        while (bi > 0 && bi * nt - bi * (bi - 1) / 2 > t) bi--;
+        while ((bi + 1) * nt - (bi + 1) * bi / 2 <= t) bi++;
+        const uint64_t bj = bi + (t - (bi * nt - bi * (bi - 1) / 2));
+        __syncthreads();
+        for (int r = ty; r < TS; r += kBlock / TS) {
+            const uint64_t iu = bi * TS + r, ju = bj * TS + tx;       // element (iu, ju) of the upper tile
+            const uint64_t il = bj * TS + r, jl = bi * TS + tx;       // element (il, jl) of its mirror image
+            s_up[r][tx] = (iu < n && ju < n) ? elem_as_double(A[iu * lda + ju]) : 0.0;
+            s_lo[r][tx] = (il < n && jl < n) ? elem_as_double(A[il * lda + jl]) : 0.0;
+        }
+        __syncthreads();
+        for (int r = ty; r < TS; r += kBlock / TS) {
+            const double u = s_up[r][tx], l = s_lo[tx][r];             // A[bi*TS + r][bj*TS + tx] and A[bj*TS + tx][bi*TS + r]
+            const double d = fabs(u - l), v = fmax(fabs(u), fabs(l));
             m = d > m ? d : m;
+            a = v > a ? v : a;
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off, 64), q = __shfl_xor(a, off, 64);
+        m = o > m ? o : m;
+        a = q > a ? q : a;
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[0][threadIdx.x >> 6] = m; s_max[1][threadIdx.x >> 6] = a; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = s_max[0];
-        for (int w = 1; w < kWaves; w++) t = s_max[w] > t ? s_max[w] : t;
-        out[blockIdx.x] = t;
+        double t0 = s_max[0][0], t1 = s_max[1][0];
+        for (int w = 1; w < kWaves; w++) { t0 = s_max[0][w] > t0 ? s_max[0][w] : t0; t1 = s_max[1][w] > t1 ? s_max[1][w] : t1; }
+        out[blockIdx.x] = t0;
+        out[gridDim.x + blockIdx.x] = t1;
     }
 }
 
@@ -1755,8 +1783,8 @@ wait_p_kernel(const Mail *mine, int nranks, int rank, BlockCounts nb, unsigned l
 // After the GEMV every rank all-gathers [Ap_slice | its partial of p.Ap] (the reference CPU path also
 // gathers Ap, ConjugateGradient_CPU_MPI_OMP.hpp:505) and then updates FULL-length r and p
 // redundantly -- O(N) work per rank, like the reference's full-length axpby (:476) -- so r.r needs
-// no collective at all.  Layout of the gathered buffer: rank q's record starts at q*stride_bytes:
-// `base` values of TV followed by one double.
+// no collective at all.  Layout of the gathered buffer: rank q's record starts at q*stride_bytes: room for the LONGEST
+// slice (base + n % P values of TV; rank q < P-1 fills the first `base`), then -- at stride_bytes - 8 -- one double.
 // ---------------------------------------------------------------------------------------------
 template <typename TV>
 __global__ void __launch_bounds__(kBlock)
@@ -1793,7 +1821,9 @@ __device__ __forceinline__ TV gathered_ap(const char *__restrict__ gathered, uin
                                           int sum_records, uint64_t i)
 {
     if (!sum_records) {
-        const uint64_t q = i / base;
+        // the reference's partition: `base` rows per shard, the remainder on the LAST one (its record is the long one)
+        uint64_t q = i / base;
+        if (q >= (uint64_t)nranks) q = (uint64_t)nranks - 1;
         return reinterpret_cast<const TV *>(gathered + q * stride_bytes)[i - q * base];
     }
     TV v = reinterpret_cast<const TV *>(gathered)[i];

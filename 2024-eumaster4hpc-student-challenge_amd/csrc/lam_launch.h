@@ -361,6 +361,10 @@ struct Impl {
     }
 };
 
+// The typed bodies of the host code are written as generic lambdas over Impl<TA,TV>; TA / TV are recovered with this small trait.
+template <typename T> struct ImplTraits;
+template <typename TA_, typename TV_> struct ImplTraits<Impl<TA_, TV_>> { using TA = TA_; using TV = TV_; };
+
 // Own-slice panel [lo,hi) of the CG GEMV, or lo == hi when the GEMV stays one launch.  Panels need
 // 16-byte aligned segment starts (lo, hi multiples of the vector width) unless the generic kernel runs.
 template <typename I>

@@ -8,7 +8,7 @@ usage: run_ranks.py P N mode [--overlap 0|1] [--exchange 0|1|2] [--finalize 0|1]
 --chunk C runs the solve as repeated lam_hip_cg_iterate(C) calls (the stop has to be noticed across
 calls, and every rank must leave the loop after the same call).
 mode file: --matrix / --rhs name files in the reference's format (every rank reads its own row block), N is ignored.
-Unless --no-single is given the same system is also solved on ONE shard and -- n <= 4096 -- by the CPU ORACLE with the
+Unless --no-single is given the same system is also solved on ONE shard and -- n <= 5000 -- by the CPU ORACLE with the
 same number of (emulated) ranks (oracle.cg_solve(..., P=P): the reference's MPI recurrence, CPU_MPI_OMP.hpp:71-142), and
 the residual is recomputed with numpy: every multi-rank case is tied to the reference algorithm, not only to another
 run of the HIP path."""
@@ -132,11 +132,11 @@ def main():
             s.solve(iters, tol)
             x1, it1 = s.solution(), s.stats["num_iters"]
             y1 = s.gemv(xprobe)
-            if n <= 4096:
+            if n <= 5000:
                 A_host, b_host = s.download_rows(0, n), s.rhs()       # what the device holds (bf16: the rounded matrix)
         res.update(iters_single=it1, x_vs_single=float(np.linalg.norm(out[0]["x"] - x1) / np.linalg.norm(x1)),
                    gemv_vs_single=float(np.max(np.abs(out[0]["y"] - y1)) / np.max(np.abs(y1))))
-        if n <= 4096:
+        if n <= 5000:
             # ... and the reference algorithm itself on the same system, with the same number of ranks
             from oracle import pyoracle
             x_or, st_or = pyoracle.cg_solve(A_host.astype(vdt), b_host.astype(vdt), iters, tol, P=P)

@@ -630,12 +630,14 @@ def test_randomised_sizes_and_shards(lam, oracle):
 
 def test_randomised_sizes_and_shards_symmetric(lam, oracle):
     """The same drill with option symmetric = 2: random sizes (rows shorter than a vector, than a strip; odd and even N -- the
-    antipode rule --; ragged last strips and last tasks), 1 ... 6 row shards (N a multiple of the shard count: the gather-Ap
-    exchange), every storage type; a few iterations against the fp64 oracle on the matrix the device holds."""
+    antipode rule --; ragged last strips and last tasks), 1 ... 6 row shards (the gather-Ap exchange; every other case with the
+    reference's uneven partition), every storage type; a few iterations against the fp64 oracle on the matrix the device holds."""
     rng = np.random.default_rng(4202)
     for case in range(40):
         P = int(rng.integers(1, 7))
         n = P * int(rng.integers(1, 1500 // P + 1))
+        if case % 2 == 1:
+            n += int(rng.integers(0, P))                 # the reference's uneven partition: the remainder goes to the last shard
         dt_name = ["F64", "F64", "F32", "BF16"][int(rng.integers(0, 4))]
         q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
         A = (q * np.exp(1.5 * rng.uniform(-1, 1, n))) @ q.T
@@ -646,10 +648,7 @@ def test_randomised_sizes_and_shards_symmetric(lam, oracle):
             s.set_matrix(A)
             s.set_rhs(b)
             s.set_option("symmetric", 2)
-            # several shards: the gather-Ap exchange wants the slice's bytes a multiple of 8 (fp32 vectors: an even slice); else the
-            # context stays on the sliced-vector exchange and on the general GEMV
-            expect = 1 if P == 1 or ((n // P) * (8 if dt_name == "F64" else 4)) % 8 == 0 else 0
-            assert s.get_option("symmetric_effective") == expect, (case, n, P, dt_name)
+            assert s.get_option("symmetric_effective") == 1, (case, n, P, dt_name)      # any N >= P, any storage type (round 5)
             A_dev = s.download_rows(0, n).astype(np.float64)
             assert np.array_equal(A_dev, A_dev.T)
             s.solve(k, 1e-30)
@@ -755,7 +754,9 @@ def test_symmetric_option_preconditions(lam):
 
 @pytest.mark.parametrize("dtype_name,n,shards", [("F64", 4096, 2), ("F64", 3000, 3), ("F64", 8192, 8), ("F64", 1002, 3), ("F64", 1000, 4),
                                                  ("F32", 4096, 4), ("F64", 12288, 4), ("F64", 49152, 8), ("F64", 64, 2), ("F64", 2050, 2),
-                                                 ("BF16", 4096, 2), ("BF16", 6000, 3)])
+                                                 ("BF16", 4096, 2), ("BF16", 6000, 3),
+                                                 # the reference's uneven partition (remainder on the last shard), odd N, fp32 records with an odd length
+                                                 ("F64", 1001, 3), ("F64", 5000, 6), ("F32", 1001, 3), ("F64", 4099, 5), ("BF16", 3001, 4)])
 def test_symmetric_product_on_several_shards(lam, dtype_name, n, shards):
     """Option "symmetric" with several row shards in one process (gather-Ap exchange): every row takes the cyclic window of
     (N-1)/2 columns behind its diagonal (for even N the antipode goes to the upper half's rows), so every pair {i, j} is read
@@ -862,14 +863,20 @@ def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
 
 
 @pytest.mark.parametrize("shards,n,dtype_name", [(2, 1024, "F64"), (4, 4096, "F64"), (8, 8192, "F64"), (3, 3000, "F64"), (8, 4104, "F64"),
-                                                  (4, 2048, "F32"), (2, 1000, "F64"), (5, 1000, "F64")])
-def test_one_process_gather_ap_exchange(lam, shards, n, dtype_name):
+                                                  (4, 2048, "F32"), (2, 1000, "F64"), (5, 1000, "F64"),
+                                                  # the reference's uneven partition (n / P rows each, the remainder on the LAST shard,
+                                                  # gathered with MPI_Allgatherv, CPU_MPI_OMP.hpp:176-196,505): records of the longest slice
+                                                  (3, 1001, "F64"), (3, 4098, "F64"), (6, 5000, "F64"), (5, 1001, "F64"), (7, 1000, "F32"),
+                                                  (3, 1001, "F32"), (16, 1039, "F64")])
+def test_one_process_gather_ap_exchange(lam, oracle, shards, n, dtype_name):
     """One process, several shards, option exchange = 1 (gather-Ap): every shard's GEMV stores its Ap slice and its p.Ap
     partial straight into every shard's gather buffer, ONE join per iteration (through shard 0's stream, or all-to-all
     with exchange_join 0), r and p full-length on every shard (the reference CPU path's layout,
     ConjugateGradient_CPU_MPI_OMP.hpp:476,505).  Both joins give the same bits, also when the solve is cut into calls;
-    the result agrees with the three-exchange default to the recursion's sensitivity, its recomputed residual meets
-    the tolerance, and sizes the exchange cannot take (N not a multiple of the shard count) run on exchange 0."""
+    the result agrees with the three-exchange form to the recursion's sensitivity, its recomputed residual meets
+    the tolerance, and -- round 5 -- ANY N >= shards runs on it (no fallback): the reference's partition with the remainder on the
+    last shard included.  fp64 cases up to n = 5000 are also held against the ORACLE with the same number of emulated ranks
+    (the reference's MPI recurrence) under the file-mode gates."""
     dt = getattr(lam, dtype_name)
     tol = 1e-9 if dtype_name == "F64" else 1e-5
     res = {}
@@ -892,9 +899,12 @@ def test_one_process_gather_ap_exchange(lam, shards, n, dtype_name):
                 s.cg_iterate(chunk, 0.0)
             out["launches"] = (s.get_option("hip_calls_launch") - l0) / 42
             out["x42"], out["err42"] = s.solution(), s.stats["rel_err"]
+            if label == "gather_ap" and dtype_name == "F64" and n <= 5000:
+                out["A"], out["b"] = s.download_rows(0, n), s.rhs()
+                out["parts"] = [s.partition(q) for q in range(shards)]
             res[label] = out
     a, b, e, t = res["gather_ap"], res["gather_ap_all_to_all"], res["events"], res["gather_ap_two_kernels"]
-    assert a["eff"] == b["eff"] == t["eff"] == (1 if n % shards == 0 else 0) and e["eff"] == 0
+    assert a["eff"] == b["eff"] == t["eff"] == 1 and e["eff"] == 0
     for k in ("iters", "err", "err42"):
         assert a[k] == b[k] == t[k], k
     assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["x42"], b["x42"])
@@ -903,22 +913,27 @@ def test_one_process_gather_ap_exchange(lam, shards, n, dtype_name):
         # the full-length vector step in ONE launch (update_full_fused_kernel) or as two kernels: GEMV + 1 or GEMV + 2 per shard
         assert (a["fused"], t["fused"]) == (1, 0)
         assert abs(a["launches"] - 2 * shards) < 0.01 and abs(t["launches"] - 3 * shards) < 0.01, (a["launches"], t["launches"])
-    if a["eff"] == 0:                                   # fell back: the very same path as the default
-        assert np.array_equal(a["x"], e["x"]) and a["iters"] == e["iters"]
     assert abs(a["iters"] - e["iters"]) <= 2
+    if "A" in a:
+        # the reference algorithm itself with the same number of (emulated) ranks on the same system: file-mode gates
+        assert a["parts"] == [oracle.partition(n, shards, q) for q in range(shards)]
+        x_or, st_or = oracle.cg_solve(a["A"], a["b"], 500, tol, P=shards)
+        assert st_or["converged"] and abs(a["iters"] - st_or["num_iters"]) <= max(3, 0.02 * st_or["num_iters"]), (a["iters"], st_or)
+        assert np.linalg.norm(a["b"] - a["A"] @ a["x"]) / np.linalg.norm(a["b"]) <= 2 * tol + 1e-13
+        assert np.linalg.norm(a["x"] - x_or) / np.linalg.norm(x_or) <= 10 * tol
     assert a["res"] <= 2 * tol + 1e-13 and a["err"] < tol
     assert np.linalg.norm(a["x"] - e["x"]) / np.linalg.norm(e["x"]) <= (1e-8 if dtype_name == "F64" else 1e-3)
     assert np.linalg.norm(a["x42"] - e["x42"]) / np.linalg.norm(e["x42"]) <= (1e-9 if dtype_name == "F64" else 1e-3)
 
 
-@pytest.mark.parametrize("shards", [2, 4])
+@pytest.mark.parametrize("shards", [2, 3, 4, 6, 7])
 def test_one_process_gather_ap_file_mode_golden(lam, oracle, golden, shards):
     """The reference's own fixtures on the gather-Ap exchange (same gates as test_cg_file_mode_golden)."""
     ran = 0
     for g in golden["file_mode"]:
-        if g["n"] % shards != 0:
+        if g["n"] < shards:
             continue
-        _check_against_golden(lam, oracle, g, shards, exchange=1)
+        _check_against_golden(lam, oracle, g, shards, exchange=1)      # n = 100 on 3 / 6 / 7 shards: the uneven partition
         ran += 1
     assert ran >= 3
 
