@@ -77,7 +77,9 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         _stats = st;
         if (_print_csv && is_root()) {
             if (_comm_init_column) std::cout << st.t_comm_init << ",";
-            std::cout << st.t_gemv << "," << st.t_iter << "," << st.num_iters << "," << st.rel_err << ",";
+            // the reference's t_gemv column includes its broadcast + gather (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:352-377);
+            // here the default column is the GEMV kernel alone and gemv_plus_comm adds the exchange step(s) to it
+            std::cout << (_gemv_plus_comm ? st.t_gemv + st.t_exchange : st.t_gemv) << "," << st.t_iter << "," << st.num_iters << "," << st.rel_err << ",";
         }
         if (_print_text && is_root()) {
             if (st.converged)
@@ -284,6 +286,9 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
     lam_hip_ctx *context() { return ensure_ctx() ? _ctx : nullptr; }
     void set_csv_output(bool on) { _print_csv = on; }
     void set_text_output(bool on) { _print_text = on; }
+    // CSV: print t_gemv + t_exchange in the GEMV column (the reference's convention); also switched on by the environment
+    // variable LAM_CSV_GEMV_PLUS_COMM=1 (for drivers compiled from the reference's own sources)
+    void set_gemv_plus_comm(bool on) { _gemv_plus_comm = on; }
 
   protected:
     // derived classes create the context (which devices, which exchange)
@@ -292,6 +297,11 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
     bool ensure_ctx() const
     {
         if (_ctx) return true;
+        // the stats struct and the option semantics belong to one ABI version: a library of another one is refused, not guessed at
+        if (lam_hip_abi_version() != LAM_HIP_ABI_VERSION) {
+            fprintf(stderr, "LAM HIP: liblam_hip.so has ABI %d, these headers were written for ABI %d\n", lam_hip_abi_version(), LAM_HIP_ABI_VERSION);
+            return false;
+        }
         auto *self = const_cast<ConjugateGradient_HIP_base *>(this);
         if (!self->create_context(&self->_ctx) || !_ctx) {
             fprintf(stderr, "LAM HIP: cannot create the GPU context: %s\n", lam_hip_last_error(nullptr));
@@ -327,6 +337,7 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
     bool _print_csv = false;          // the getopt-style drivers' CSV fragments
     bool _print_text = false;         // the positional drivers' "Converged in ..." line
     bool _comm_init_column = false;   // extra column of the NCCL variant
+    bool _gemv_plus_comm = [] { const char *v = getenv("LAM_CSV_GEMV_PLUS_COMM"); return v && *v && *v != '0'; }();
     lam_hip_stats _stats{};
 };
 

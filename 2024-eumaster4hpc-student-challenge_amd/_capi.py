@@ -15,6 +15,7 @@ _LIB = os.environ.get("LAM_HIP_LIB") or os.path.join(_HERE, "liblam_hip.so")
 TUNING_LIB = os.path.join(_HERE, "liblam_hip_tuning.so")
 
 F64, F32, BF16 = 0, 1, 2
+ABI_VERSION = 4     # include/lam_hip.h LAM_HIP_ABI_VERSION
 _VEC_DTYPE = {F64: np.float64, F32: np.float32, BF16: np.float32}
 _HOST_MAT_DTYPE = {F64: np.float64, F32: np.float32, BF16: np.float32}
 
@@ -28,7 +29,7 @@ class LamHipError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("num_iters", C.c_int32), ("converged", C.c_int32), ("rel_err", C.c_double),
                 ("t_gemv", C.c_double), ("t_iter", C.c_double), ("t_total", C.c_double),
-                ("t_comm_init", C.c_double), ("gemv_bytes", C.c_double)]
+                ("t_comm_init", C.c_double), ("gemv_bytes", C.c_double), ("t_exchange", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -126,6 +127,8 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the library does not export it
             fn.argtypes, fn.restype = args, res
         L._lam_symbols = tuple(sig)
+        if L.lam_hip_abi_version() != ABI_VERSION:      # the Stats struct above belongs to one ABI version
+            raise ImportError(f"{_LIB} has ABI {L.lam_hip_abi_version()}, this binding was written for ABI {ABI_VERSION}")
         built, want = L.lam_hip_build_id().decode(), source_id()
         if want is not None and built != want and not os.environ.get("LAM_HIP_ALLOW_STALE"):
             raise ImportError(f"{_LIB} was built from other sources (library {built}, sources {want}): rebuild it "

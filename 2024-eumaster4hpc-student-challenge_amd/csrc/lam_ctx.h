@@ -63,6 +63,8 @@ struct ShardBase {
     hipEvent_t ev_g2[kLag] = {}, ev_g3[kLag] = {};              // second panel of a split GEMV
     bool split_slot[kLag] = {};
     bool timed_slot[kLag] = {};                                 // the slot's iteration recorded its timing events
+    hipEvent_t ev_x[kLag][6] = {};                              // exchange timing ring (shard 0): up to three begin / end pairs per timed
+    int nx[kLag] = {};                                          // iteration -- one per exchange step (lam_exchange.h, xt_begin / xt_end)
     // in-launch hand-over / direct exchange (lam_kernels.h, Mail): the shard's mailbox (fine-grained device memory where
     // the runtime offers it), the broadcast lines of its fused update launch, and the iteration whose fused launch has
     // already waited for the peers' p slices.  Kept for the life of the context.
@@ -164,6 +166,8 @@ struct lam_hip_ctx {
     int *direct_err = nullptr;                  // pinned host: a bounded in-kernel wait expired ([0] = which, see cg_iterate)
     double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
+    int xt_slot = -1;              // timing-ring slot of the iteration being enqueued if that iteration is timed (option gemv_timing),
+                                   // else -1: its exchange steps are bracketed with HIP events too (lam_hip_stats.t_exchange)
     int ranks_on_device = 1;       // rank mode: ranks of the communicator that share THIS rank's GPU (emulations; counted once at
                                    // creation over the communicator): their fused vector-step launches must all be resident together
     bool symmetric_from_env = false;   // option "symmetric" came from LAM_HIP_SYMMETRIC (a driver that cannot call set_option): the

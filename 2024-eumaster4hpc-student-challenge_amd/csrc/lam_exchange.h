@@ -134,6 +134,10 @@ int create_common(lam_hip_ctx *c)
                 hipEventCreate(&s.ev_g2[i]) != hipSuccess || hipEventCreate(&s.ev_g3[i]) != hipSuccess)
                 return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
         }
+        if (&s == &c->sh[0])
+            for (int i = 0; i < kLag; i++)
+                for (auto &ev : s.ev_x[i])
+                    if (hipEventCreate(&ev) != hipSuccess) return fail(nullptr, LAM_HIP_EHIP, "hipEventCreate failed");
     }
     // hub of the one-process exchange (see hub_join): a stream on shard 0's device and one join event per exchange
     if (!c->rank_mode && c->sh.size() > 1) {
@@ -214,6 +218,28 @@ int sync_all(lam_hip_ctx *c)
     return 0;
 }
 
+// Exchange timing (lam_hip_stats.t_exchange; the reference's t_gemv column INCLUDES its broadcast + gather,
+// ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:352-377 -- here the two are separate numbers).  In an iteration whose GEMV is timed
+// (option gemv_timing: every T-th) shard 0 / this rank also brackets every EXCHANGE step with a HIP-event pair on the stream the
+// step runs on: the collective(s) of the rank mode, the event join(s) of one process driving several shards (from the post behind
+// the producer kernel to the point where the consumer's stream has passed its waits -- what the peers' skew costs is part of it).
+// Up to three steps per iteration (exchange 0: p.Ap, r.r, p slices -- the last one on the comm stream, where it overlaps the next
+// GEMV's own-slice panel; gather-Ap: one).  One shard and the direct exchange have none (the latter waits inside its kernels).
+bool xt_on(const lam_hip_ctx *c, const ShardBase &s) { return c->xt_slot >= 0 && &s == &c->sh[0] && s.nx[c->xt_slot] < 3; }
+int xt_begin(lam_hip_ctx *c, ShardBase &s, hipStream_t st)
+{
+    if (!xt_on(c, s)) return 0;
+    RECORD(c, s.ev_x[c->xt_slot][2 * s.nx[c->xt_slot]], st);
+    return 0;
+}
+int xt_end(lam_hip_ctx *c, ShardBase &s, hipStream_t st)
+{
+    if (!xt_on(c, s)) return 0;
+    RECORD(c, s.ev_x[c->xt_slot][2 * s.nx[c->xt_slot] + 1], st);
+    s.nx[c->xt_slot]++;
+    return 0;
+}
+
 // Does the producer launch of this dot product carry a reducer workgroup (lam_kernels.h, Finalize)?  The
 // symmetric product's second pass writes plain per-workgroup partials of p.Ap: its consumer sums them.
 bool producer_reduces(const lam_hip_ctx *c, bool second) { return c->opt_finalize != 0 && (second || !c->symv_active()); }
@@ -270,12 +296,14 @@ int reduce_post(lam_hip_ctx *c, ShardBase &s, bool second, bool use_gemv_part, b
                            check_stop ? (const CgScalars *)s.sc : (const CgScalars *)nullptr);
         LAUNCHED(c);
     }
+    LAMCHK(xt_begin(c, s, s.stream));
     if (c->rank_mode) {
         double *buf = second ? s.gather_b : s.gather_a;
         NCCLCHK(c, ncclAllGather(buf + c->rank, buf, 1, ncclDouble, c->comm, s.stream));
         c->n_collectives++;
+        LAMCHK(xt_end(c, s, s.stream));
     } else {
-        RECORD(c, second ? s.ev_b : s.ev_a, s.stream);
+        RECORD(c, second ? s.ev_b : s.ev_a, s.stream);       // the step ends in reduce_wait, behind this stream's waits
     }
     return 0;
 }
@@ -304,10 +332,10 @@ int hub_join(lam_hip_ctx *c, int which)
 int reduce_wait(lam_hip_ctx *c, ShardBase &s, bool second)
 {
     if (c->rank_mode || c->total_shards == 1) return 0;
-    if (hub_active(c)) { WAITEV(c, s.stream, c->ev_join[second ? 1 : 0]); return 0; }
+    if (hub_active(c)) { WAITEV(c, s.stream, c->ev_join[second ? 1 : 0]); return xt_end(c, s, s.stream); }
     for (auto &t : c->sh)
         if (&t != &s) WAITEV(c, s.stream, second ? t.ev_b : t.ev_a);
-    return 0;
+    return xt_end(c, s, s.stream);
 }
 
 // both halves for all shards from one thread (cg_init)
@@ -352,9 +380,11 @@ int gather_p_rank(lam_hip_ctx *c)
         RECORD(c, s.ev_p, s.stream);
         WAITEV(c, cs, s.ev_p);
     }
+    LAMCHK(xt_begin(c, s, cs));
     struct Done {   // record ev_gathered on every exit path below
         lam_hip_ctx *c; ShardBase &s; hipStream_t cs;
         int finish() {
+            LAMCHK(xt_end(c, s, cs));
             if (!c->opt_overlap) return 0;
             RECORD(c, s.ev_gathered, cs);
             c->gather_pending = true;
@@ -384,16 +414,17 @@ int gather_p_rank(lam_hip_ctx *c)
 int gather_post(lam_hip_ctx *c, ShardBase &s)
 {
     if (c->rank_mode || c->total_shards == 1) return 0;
+    LAMCHK(xt_begin(c, s, s.stream));
     RECORD(c, s.ev_p, s.stream);
     return 0;
 }
 int gather_wait(lam_hip_ctx *c, ShardBase &s)
 {
     if (c->rank_mode || c->total_shards == 1) return 0;
-    if (hub_active(c)) { WAITEV(c, s.stream, c->ev_join[2]); return 0; }
+    if (hub_active(c)) { WAITEV(c, s.stream, c->ev_join[2]); return xt_end(c, s, s.stream); }
     for (auto &t : c->sh)
         if (&t != &s) WAITEV(c, s.stream, t.ev_p);
-    return 0;
+    return xt_end(c, s, s.stream);
 }
 
 // make every replica of p complete after the slices were stored (all shards, one thread: cg_init)
@@ -846,6 +877,7 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
                     LAUNCHED(c);
                 }
                 if (timed) RECORD(c, s.ev_g1[slot], s.stream);
+                LAMCHK(xt_begin(c, s, s.stream));
                 if (!(c->opt_join && &s == &c->sh[0])) RECORD(c, s.ev_a, s.stream);
                 continue;
             }
@@ -870,6 +902,7 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
                                    f.dst, 0, (const CgScalars *)s.sc);
                 LAUNCHED(c);
             }
+            LAMCHK(xt_begin(c, s, s.stream));
             if (!(c->opt_join && &s == &c->sh[0])) RECORD(c, s.ev_a, s.stream);
         }
         // the join
@@ -878,6 +911,7 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
             LAMCHK(set_dev(c, s0));
             for (auto &t : c->sh)
                 if (&t != &s0) WAITEV(c, s0.stream, t.ev_a);
+            LAMCHK(xt_end(c, s0, s0.stream));
             RECORD(c, c->ev_join[0], s0.stream);
         }
         const int grid = vec_grid(c->n);
@@ -890,6 +924,7 @@ int enqueue_iteration_exchange1_local(lam_hip_ctx *c, int k, double rel_error, i
             } else {
                 for (auto &t : c->sh)
                     if (&t != &s) WAITEV(c, s.stream, t.ev_a);
+                LAMCHK(xt_end(c, s, s.stream));
             }
             if (c->fuse_active) {
                 // the two vector kernels in ONE launch (r.r resolved by its reducer workgroup): 2 launches per shard and iteration
@@ -999,8 +1034,10 @@ int enqueue_iteration_exchange1(lam_hip_ctx *c, int k, double rel_error, int slo
             LAUNCHED(c);
         }
         // 2. the iteration's only collective
+        LAMCHK(xt_begin(c, s, s.stream));
         NCCLCHK(c, ncclAllGather(rec, gathered, stride, ncclChar, c->comm, s.stream));
         c->n_collectives++;
+        LAMCHK(xt_end(c, s, s.stream));
         // 3. alpha, x slice, FULL r (+ partials of r.r over the full vector: no collective needed)
         const int grid = vec_grid(c->n);
         if (c->fuse_active) {

@@ -578,7 +578,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     } cpu_account{c, cpu0};
     ShardBase &s0 = c->sh[0];
     c->prog_t = 0.0;               // the estimate of the iteration time carries over, the reference point does not
-    double gemv_ms = 0.0;
+    double gemv_ms = 0.0, xch_ms = 0.0;
     int gemv_samples = 0;
     int enq = 0;
     // already converged in an earlier call?
@@ -587,7 +587,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     HIPCHK(c, hipStreamSynchronize(s0.stream));
     const bool stopped = s0.sc_host->stop != 0;
     const int k_first = c->k_done + 1;
-    for (int i = 0; i < kLag; i++) s0.timed_slot[i] = false;
+    for (int i = 0; i < kLag; i++) { s0.timed_slot[i] = false; s0.nx[i] = 0; }
     if (stopped) {
         // nothing to enqueue
     }
@@ -613,7 +613,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             enq += cnt;
         }
     } else if (!c->rank_mode && c->total_shards > 1 && c->opt_host_threads != 0 && !c->cg_direct && !c->cg_exchange1) {
-        LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &gemv_ms, &gemv_samples));
+        LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &gemv_ms, &gemv_samples, &xch_ms));
         c->gather_pending = false;
     }
 #endif
@@ -626,7 +626,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
                 const int d = lag_check(c, s0, k);
                 if (d < 0) return d;
                 if (d != 0) break;
-                harvest_gemv_time(s0, slot, &gemv_ms, &gemv_samples);
+                harvest_gemv_time(s0, slot, &gemv_ms, &gemv_samples, &xch_ms);
             }
             const double te = now_s();
             LAMCHK(enqueue_iteration(c, k, rel_error, slot));
@@ -663,7 +663,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         LAMCHK(lam_hip_all_ok(c, 1, &all));
     }
     // harvest the GEMV timings still in the ring
-    for (int j = 0; j < kLag; j++) harvest_gemv_time(s0, j, &gemv_ms, &gemv_samples);
+    for (int j = 0; j < kLag; j++) harvest_gemv_time(s0, j, &gemv_ms, &gemv_samples, &xch_ms);
     LAMCHK(set_dev(c, s0));
     HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
     HIPCHK(c, hipStreamSynchronize(s0.stream));
@@ -680,6 +680,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         st->t_total = t1 - t0;
         st->t_iter = ran > 0 ? (t1 - t0) / ran : 0.0;
         st->t_gemv = gemv_samples > 0 ? gemv_ms * 1e-3 / gemv_samples : 0.0;
+        st->t_exchange = gemv_samples > 0 ? xch_ms * 1e-3 / gemv_samples : 0.0;
 #ifdef LAM_TUNING_VARIANTS
         if (c->persist_active && c->persist_ticks != nullptr) {
             // the persistent launch times its GEMV phases itself (constant-rate 100 MHz counter, reducer workgroup):
@@ -1178,6 +1179,13 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
     else if (!strcmp(name, "reuse_matrix")) *value = c->opt_reuse_matrix;
     else if (!strcmp(name, "fuse_update")) *value = c->opt_fuse;
     else if (!strcmp(name, "collectives_enqueued")) *value = (int64_t)c->n_collectives;
+    else if (!strcmp(name, "rccl_ranks")) {
+        // the size of the communicator AS RCCL REPORTS IT (ncclCommCount), 0 without one: "did RCCL see N ranks" (bench.py)
+        int count = 0;
+        if (c->comm != nullptr && ncclCommCount(c->comm, &count) != ncclSuccess) count = -1;
+        *value = count;
+    }
+    else if (!strcmp(name, "ranks_on_device")) *value = c->ranks_on_device;
     else if (!strcmp(name, "tuning_variants")) *value = Impl<double, double>::variant_available(1) ? 1 : 0;
     else if (!strcmp(name, "fuse_effective")) *value = c->fuse_active ? 1 : 0;
     else if (!strcmp(name, "persistent")) *value = c->opt_persistent;

@@ -241,7 +241,20 @@ int phase_p(lam_hip_ctx *c, ShardBase &s, int k, double rel_error)
     return gather_post(c, s);
 }
 
+int enqueue_iteration_body(lam_hip_ctx *c, int k, double rel_error, int slot);
+
+// one iteration, all local shards; if its GEMV is timed, so are its exchange steps (xt_begin / xt_end, shard 0)
 int enqueue_iteration(lam_hip_ctx *c, int k, double rel_error, int slot)
+{
+    ShardBase &s0 = c->sh[0];
+    s0.nx[slot] = 0;
+    c->xt_slot = timed_iteration(c, s0, k) ? slot : -1;
+    const int rc = enqueue_iteration_body(c, k, rel_error, slot);
+    c->xt_slot = -1;
+    return rc;
+}
+
+int enqueue_iteration_body(lam_hip_ctx *c, int k, double rel_error, int slot)
 {
     if (c->cg_direct) return enqueue_iteration_direct(c, k, rel_error, slot);
     if (c->cg_exchange1) return enqueue_iteration_exchange1(c, k, rel_error, slot);
@@ -384,15 +397,32 @@ struct HostBarrier {
 #endif
 
 
-// GEMV device time of the iteration that used ring slot `slot` (shard 0), if that iteration was timed
-static void harvest_gemv_time(ShardBase &s0, int slot, double *ms_sum, int *samples)
+// GEMV device time of the iteration that used ring slot `slot` (shard 0), if that iteration was timed, and the time of its exchange
+// steps (xt_begin / xt_end pairs)
+static void harvest_gemv_time(ShardBase &s0, int slot, double *ms_sum, int *samples, double *xch_ms_sum)
 {
     if (!s0.timed_slot[slot]) return;
     s0.timed_slot[slot] = false;
+    const int nx = s0.nx[slot];
+    s0.nx[slot] = 0;
     float ms = 0.f, ms2 = 0.f;
     if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
     if (s0.split_slot[slot] && hipEventElapsedTime(&ms2, s0.ev_g2[slot], s0.ev_g3[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
+    double xms = 0.0;
+    for (int j = 0; j < nx; j++) {
+        float x = 0.f;
+        hipError_t e = hipEventElapsedTime(&x, s0.ev_x[slot][2 * j], s0.ev_x[slot][2 * j + 1]);
+        if (e == hipErrorNotReady) {
+            // the all-gather of p runs on the comm stream and may still be in flight when its iteration has reported (a few
+            // microseconds: the next GEMV's second panel waits for it)
+            (void)hipGetLastError();
+            if (hipEventSynchronize(s0.ev_x[slot][2 * j + 1]) == hipSuccess) e = hipEventElapsedTime(&x, s0.ev_x[slot][2 * j], s0.ev_x[slot][2 * j + 1]);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); return; }
+        xms += x;
+    }
     *ms_sum += ms + ms2;
+    *xch_ms_sum += xms;
     (*samples)++;
 }
 
@@ -423,7 +453,7 @@ static int lag_check(lam_hip_ctx *c, ShardBase &s0, int k)
 // from its own OpenMP thread, ConjugateGradient_MultiGPUS_CUDA.cu:264-283,337-378).  With one thread for P shards an
 // iteration costs the host 3P launches + ~3P event records + 3P(P-1) stream waits one after the other; here they are
 // issued P-wide, with a host barrier between the phases (a stream wait must follow the record it refers to).
-static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_error, int *enq_out, double *gemv_ms, int *gemv_samples)
+static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_error, int *enq_out, double *gemv_ms, int *gemv_samples, double *xch_ms)
 {
     const int L = (int)c->sh.size();
     HostBarrier bar(L);
@@ -447,7 +477,7 @@ static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_e
                     const int d = lag_check(c, s, k);
                     if (d < 0) { rc = d; flags |= 1; }
                     else if (d != 0) flags |= 2;
-                    else harvest_gemv_time(s, slot, gemv_ms, gemv_samples);
+                    else harvest_gemv_time(s, slot, gemv_ms, gemv_samples, xch_ms);
                 }
                 if (bar.wait(flags) != 0) break;
             }

@@ -451,6 +451,8 @@ void release_handles(ShardBase &s)
         hipEvent_t *ring[] = {&s.ev_g0[i], &s.ev_g1[i], &s.ev_g2[i], &s.ev_g3[i]};
         for (auto e : ring) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     }
+    for (int i = 0; i < kLag; i++)
+        for (auto &e : s.ev_x[i]) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (s.comm_stream) { (void)hipStreamSynchronize(s.comm_stream); (void)hipStreamDestroy(s.comm_stream); s.comm_stream = nullptr; }
     if (s.stream) { (void)hipStreamSynchronize(s.stream); (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
 }

@@ -42,6 +42,7 @@ void usage(const char *exe)
     printf("                  exp(3.5 U[-1,1]), rhs U[-1,1], its srand/rand streams), built on the device without the files\n");
     printf("  -t <type>       f64 (default, what the reference drivers hard-code), f32, or bf16 (bf16 matrix\n");
     printf("                  storage, fp32 vectors); files hold doubles for f64 and floats otherwise\n");
+    printf("  -g              CSV: the GEMV column is GEMV + exchange (collectives / joins), the reference's convention\n");
     printf("  -v              Verbose mode\n");
     printf("  -h              Show this help message\n");
 }
@@ -55,7 +56,7 @@ struct Options {
     long seed = -1;
     int ref_seed = 0;
     bool have_ref_seed = false;
-    bool verbose = false, mode_generate = false, mode_load = false, bf16_storage = false;
+    bool verbose = false, mode_generate = false, mode_load = false, bf16_storage = false, gemv_plus_comm = false;
 };
 
 template <typename T>
@@ -92,7 +93,7 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
     const char *precision = "f64";
 
     int opt;
-    while ((opt = getopt(argc, argv, "hvA:b:o:i:e:s:r:R:c:t:")) != -1) {
+    while ((opt = getopt(argc, argv, "hvgA:b:o:i:e:s:r:R:c:t:")) != -1) {
         switch (opt) {
         case 'A':
         case 'b':
@@ -118,6 +119,7 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
         case 'R': o.ref_seed = atoi(optarg); o.have_ref_seed = true; break;
         case 'c': cond = atof(optarg); break;
         case 't': precision = optarg; break;
+        case 'g': o.gemv_plus_comm = true; break;
         case 'v': verbose = true; break;
         case 'h':
             if (root) usage(argv[0]);
@@ -163,6 +165,7 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     const bool verbose = o.verbose, mode_generate = o.mode_generate, root = L.rank == 0;
     LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<T> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id, o.bf16_storage);
     cg.set_csv_output(!verbose);
+    if (o.gemv_plus_comm) cg.set_gemv_plus_comm(true);
     if (cg.context() == nullptr) return 1;      // creates the RCCL communicator (collective)
     lam_bootstrap::communicator_ready(L);
 
@@ -200,9 +203,9 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     if (root && !verbose) std::cout << t_cg;
     if (verbose && root) {
         const auto &st = cg.stats();
-        printf("%s after %d iterations, relative error %e, %f s (GEMV %.4f ms = %.1f GB/s per GPU)\n",
+        printf("%s after %d iterations, relative error %e, %f s (GEMV %.4f ms = %.1f GB/s per GPU, exchange %.4f ms)\n",
                st.converged ? "Converged" : "Did not converge", st.num_iters, st.rel_err, t_cg, st.t_gemv * 1e3,
-               st.t_gemv > 0 ? st.gemv_bytes / st.t_gemv / 1e9 : 0.0);
+               st.t_gemv > 0 ? st.gemv_bytes / st.t_gemv / 1e9 : 0.0, st.t_exchange * 1e3);
     }
     if (!cg.save_result_to_file(sol_file)) {
         if (root) fprintf(stderr, "Failed to save solution\n");

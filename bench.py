@@ -15,13 +15,24 @@ At N=1 GPU the line also carries, under "also", configs[1] (N=32768) and the siz
 published numbers for (N=10000/20000/40000, TESTS/BEST_RESULTS:362-372) with the per-iteration cost
 outside the GEMV ("other_us"); they run after the headline in the same process and context.  Under
 "config4_gemv": BASELINE configs[3], the N=131072 fp32 / bf16-storage GEMV (VALU kernel and MFMA variant).
-For N > 1 GPUs the headline is the product's DEFAULT exchange (the other exchange modes are recorded under
-"exchange_modes" only), and every line checks itself: true == recursive residual, and for N > 1 the residual of
-the one-GPU solve of the same system; a failed check prints "value": null with the reason and exits non-zero.
 
-Under a launcher (RANK/WORLD_SIZE in the environment) every rank is one process on one GPU; the ranks
-find each other through the package's own socket rendezvous (no torch in the process: torch bundles a
-second ROCm runtime and a second RCCL) and the data path is RCCL inside liblam_hip.so.
+N > 1 GPUs: ONE command measures BOTH multi-GPU topologies the product has, whichever way it is started.
+  * started by a launcher (RANK / WORLD_SIZE in the environment: the driver's torchrun line): the HEADLINE is the rank mode --
+    one process per GPU, the exchange is RCCL inside liblam_hip.so, the ranks find each other through the package's own socket
+    rendezvous (no torch in the process) -- and rank 0 also runs the one-process topology in a child process
+    ("one_process_topology");
+  * started plainly (`python bench.py --gpus N`): the HEADLINE is one process driving N shards (peer stores over xGMI ordered
+    by HIP events, the reference's ConjugateGradient_MultiGPUS_CUDA shape) and the rank mode runs as N child processes
+    ("rank_mode_rccl": value, exchange modes 0 and 1, rccl_version, rccl_ranks = the communicator size RCCL reports,
+    rccl_calls_enqueued, its own self-check).
+Every child ("leg") is started BEFORE its parent touches the GPU (a process that has initialised the GPU must not start
+children on this pool) and hands its record back through a file.  The EXPERIMENTAL exchange (option exchange = 2: in-kernel
+flags over peer-mapped memory, never yet run on separate GPUs) runs only in legs of its own: a fault there costs that leg's
+record (`{"error": ...}`), never the line.  Every N > 1 record carries `exchange_us` (HIP-event pairs around the
+collective(s) / event join(s), lam_hip_stats.t_exchange) next to `gemv_ms`: gemv + exchange is the reference's `t_gemv` column
+(ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:352-377).  The headline is always the product's DEFAULT exchange of its topology (the
+other modes are recorded under "exchange_modes" only), and every line checks itself: true == recursive residual, and for N > 1
+the residual of the one-GPU solve of the same system; a failed check prints "value": null with the reason and exits non-zero.
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (its name comes from the
 library): achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
@@ -35,8 +46,10 @@ import argparse
 import importlib
 import json
 import os
+import signal
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,6 +58,8 @@ PKG = "2024-eumaster4hpc-student-challenge_amd"
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 MFMA_VARIANTS = ((21, "MFMA v_mfma_f32_32x32x16_bf16, p as 3 bf16 terms"), (20, "MFMA, p rounded to bf16"))
 ALSO_SIZES = (32768, 10000, 20000, 40000)
+RANK_LABELS = {0: "allgather_x2+allgather_p", 1: "allgather_Ap", 2: "direct_mailboxes"}
+LOCAL_LABELS = {0: "events_x3 (p.Ap, r.r, p slices: three joins per iteration)", 1: "gather_Ap (one join per iteration)", 2: "direct_flags"}
 
 
 def under_profiler():
@@ -104,10 +119,11 @@ def settle(s, seconds):
     warm-up steps.  What it waits out is NOT a clock ramp (round 3's reading): a fresh process on an idle device runs
     its very first launches at full rate (profiles/r04_bf16_gap_probe.txt).  It is the driver wiping VRAM that another
     process (or context) has just RELEASED: the child processes that run in front of this one (CPU baseline, two PMC
-    passes) each free 34 GB at exit, the wipe runs in the background and takes HBM bandwidth from whatever runs next --
-    the same GEMV measures 3-4 % slower for a second or two after a multi-GB hipFree (same file: bf16 85.5 % of peak right
-    after a 68.7 GB free, 88.4 % two seconds later and in a fresh process).  A timed region that starts inside that window
-    would measure the neighbour's clean-up, not the rate a solve runs at.  The cold number is still reported (`value_cold`)."""
+    passes, the legs of an N > 1 run) each free tens of GB at exit, the wipe runs in the background and takes HBM bandwidth
+    from whatever runs next -- the same GEMV measures 3-4 % slower for a second or two after a multi-GB hipFree (same file:
+    bf16 85.5 % of peak right after a 68.7 GB free, 88.4 % two seconds later and in a fresh process).  A timed region that
+    starts inside that window would measure the neighbour's clean-up, not the rate a solve runs at.  The cold number is
+    still reported (`value_cold`)."""
     t0 = time.perf_counter()
     rates = []
     while True:
@@ -202,7 +218,6 @@ def measure_traffic(n):
     import csv
     import glob
     import shutil
-    import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
@@ -248,6 +263,449 @@ def traffic_record(n, n_gpus):
         return None, None
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# legs: measurements that run in child processes of their own
+# ---------------------------------------------------------------------------------------------------------------------
+def maybe_die(leg, where):
+    """Test hook (tests/test_gpu_rank_mock.py): LAM_BENCH_KILL_LEG=<leg>[:<where>] makes every process of that leg kill itself
+    at that point -- what a GPU memory fault on a peer mapping amounts to (the process is gone, nothing is written)."""
+    spec = os.environ.get("LAM_BENCH_KILL_LEG", "")
+    if not spec:
+        return
+    name, _, at = spec.partition(":")
+    if name == leg and (at or "timed") == where:
+        sys.stderr.write(f"[bench] leg {leg}: killing myself at '{where}' (LAM_BENCH_KILL_LEG)\n")
+        sys.stderr.flush()
+        os.kill(os.getpid(), signal.SIGKILL)
+
+
+def leg_command(args, leg, out_path):
+    return [sys.executable, os.path.abspath(__file__), "--leg", leg, "--leg-out", out_path, "--gpus", str(max(1, args.gpus)), "--steps", str(args.steps),
+            "--warmup", str(args.warmup), "--order", str(args.n), "--gemv-timing", str(args.gemv_timing)]
+
+
+def run_leg(args, leg, nprocs, timeout, rank_env=None, rdzv_file=None, expect_record=True):
+    """Start the `nprocs` processes of one leg (this script with --leg), wait for them, return the record rank 0 of the leg
+    wrote -- or {"error": ...} when a process died, timed out or left no record: a leg can never cost the caller its own
+    line.  rank_env(i) = extra environment of process i (None: one plain process).  Must be called BEFORE the caller touches the
+    GPU.  expect_record = False: this caller's processes are not the ones that write the record (a rank > 0 under a launcher)."""
+    work = tempfile.mkdtemp(prefix=f"lam_leg_{leg}_")
+    out_path = os.path.join(work, "record.json")
+    t0 = time.time()
+    procs = []
+    try:
+        for i in range(nprocs):
+            env = dict(os.environ)
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LAM_RDZV_FILE", "LAM_JOB_ID"):
+                env.pop(k, None)
+            if rank_env is not None:
+                env.update(rank_env(i))
+                env["LAM_RDZV_FILE"] = rdzv_file or os.path.join(work, "rdzv")
+            # stderr goes to a file of its own (a pipe nobody drains would block a chatty child) and is echoed afterwards
+            errf = open(os.path.join(work, f"stderr.{i}"), "w+")
+            procs.append(subprocess.Popen(leg_command(args, leg, out_path), env=env, stdout=subprocess.DEVNULL, stderr=errf, start_new_session=True))
+            procs[-1].errf = errf
+        deadline = t0 + timeout
+        errs = []
+        for i, p in enumerate(procs):
+            try:
+                p.wait(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                errs.append(f"process {i} did not finish within {timeout:.0f} s")
+                continue
+            p.errf.seek(0)
+            err = p.errf.read()
+            if err.strip():
+                sys.stderr.write("".join(f"[leg {leg}.{i}] {l}\n" for l in err.strip().splitlines()[-12:]))
+            if p.returncode != 0:
+                tail = (err or "").strip().splitlines()[-3:]
+                errs.append(f"process {i} exited with {'signal ' + str(-p.returncode) if p.returncode < 0 else 'code ' + str(p.returncode)}"
+                            + (": " + " | ".join(tail)[-400:] if tail else ""))
+        rec = None
+        if os.path.exists(out_path):
+            try:
+                rec = json.load(open(out_path))
+            except Exception as e:   # noqa: BLE001
+                errs.append(f"unreadable record: {e}")
+        if errs:
+            rec = dict(rec or {}, error="; ".join(errs)[:900])
+        elif rec is None:
+            rec = {"error": "the leg left no record"} if expect_record else {}
+        rec["leg_wall_s"] = time.time() - t0
+        return rec
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:400], "leg_wall_s": time.time() - t0}
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)       # its own session: the process and whatever it started
+                except OSError:
+                    pass
+                try:
+                    p.wait(timeout=10)
+                except Exception:   # noqa: BLE001
+                    pass
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def write_leg_record(path, rec):
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        json.dump(rec, f)
+    os.replace(tmp, path)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the two multi-GPU topologies
+# ---------------------------------------------------------------------------------------------------------------------
+def mode_record(steps, dt_, st_, res_, **extra):
+    rec = {"value": steps / dt_, "ms_per_step": dt_ / steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3, "exchange_us": st_["t_exchange"] * 1e6,
+           "gemv_plus_comm_ms": (st_["t_gemv"] + st_["t_exchange"]) * 1e3, "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
+    rec.update(extra)
+    return rec
+
+
+def one_gpu_reference(lam, n, iters, device):
+    """The same solve on ONE GPU (N=65536 fits one MI355X): what every multi-GPU line is checked against."""
+    with lam.Solver(lam.F64, device_ids=[device]) as ref:
+        # LAM_BENCH_SELFTEST_FAIL=1 (tests only): the reference solves a DIFFERENT system, so the check must fail
+        ref.generate_random_spd(n, 1234 + (1 if os.environ.get("LAM_BENCH_SELFTEST_FAIL") else 0), 1e6)
+        ref.generate_random_rhs(1235)
+        ref.cg_init()
+        return ref.cg_iterate(iters, 0.0)["rel_err"]
+
+
+def self_check(lam, args, n_gpus, st, true_res, rank, rdzv, symmetric=False):
+    """true == recursive residual, and with more than one GPU the residual must agree with the SAME solve on one GPU (rank 0 runs
+    it on its own device right here).  Returns (check dict, failures)."""
+    check = {"true_vs_recursive": abs(true_res / st["rel_err"] - 1) if st["rel_err"] > 0 else float("inf"), "tolerance_true_vs_recursive": 1e-6}
+    failures = []
+    if not check["true_vs_recursive"] < 1e-6:
+        failures.append(f"true residual {true_res:.15e} != recursive residual {st['rel_err']:.15e}")
+    if n_gpus > 1 and not symmetric:
+        ref_err, ref_fail = None, None
+        if rank == 0:
+            try:
+                ref_err = one_gpu_reference(lam, args.n, args.warmup + args.steps, rdzv.local_rank % max(1, lam.device_count()) if rdzv else 0)
+            except Exception as e:   # noqa: BLE001
+                ref_fail = f"one-GPU reference solve failed: {e}"[:300]
+            check["one_gpu_reference_residual"] = ref_err
+            check["tolerance_vs_one_gpu"] = 1e-9
+            if ref_err is None:
+                failures.append(ref_fail or "no one-GPU reference")
+            else:
+                check["vs_one_gpu"] = abs(st["rel_err"] / ref_err - 1)
+                if not check["vs_one_gpu"] < 1e-9:
+                    failures.append(f"residual after {args.warmup + args.steps} iterations {st['rel_err']:.15e} differs from the one-GPU solve {ref_err:.15e}")
+        if rdzv is not None:
+            rdzv.barrier()
+    check["passed"] = not failures
+    return check, failures
+
+
+def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
+    """One process per GPU (this process is one rank; RCCL inside liblam_hip.so).  part = "main": the default exchange (the
+    headline of this topology) + the other product exchanges + the symmetric option; part = "direct": the EXPERIMENTAL direct
+    exchange only (runs in a leg of its own).  Returns this rank's record (rank 0's is the one that counts)."""
+    rank, world = rdzv.rank, rdzv.size
+    uid = rdzv.broadcast(lam.get_unique_id() if rank == 0 else b"")
+    ndev = lam.device_count()          # counting devices does not initialise the GPU
+    barrier = rdzv.barrier
+    n = args.n
+
+    def max_over_ranks(dt_, st_):
+        dt_, st_["t_gemv"], st_["t_exchange"] = rdzv.max([dt_, st_["t_gemv"], st_["t_exchange"]])
+        return dt_, st_
+
+    s = lam.Solver(lam.F64, rank=rank, nranks=world, device_id=rdzv.local_rank % max(1, ndev), unique_id=uid)
+    try:
+        s.set_option("gemv_timing", args.gemv_timing)
+        rec = {"n_gpus": world, "rccl_version": lam.rccl_version(), "rccl_ranks": s.get_option("rccl_ranks"), "rccl_init_s": None,
+               "parallelism": f"row-sharded x{world}, 1 process/GPU, RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration"}
+        default_exchange = s.get_option("exchange")
+        if part == "main":
+            host_ns0 = s.get_option("host_enqueue_ns")
+            st, dt = run_config(s, n, args.warmup, args.steps, barrier, ramp_s=args.ramp if leg_name is None else min(args.ramp, 0.3))
+            maybe_die(leg_name, "main")
+            rec["kernel"] = s.gemv_kernel_name()
+            rec["cold_start"] = run_config.cold
+            rec["exchange_effective"] = s.get_option("exchange_effective")
+            rec["host_enqueue_us_per_step"] = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
+            dt, st = max_over_ranks(dt, st)
+            true_res = s.true_residual()
+            check, failures = self_check(lam, args, world, st, true_res, rank, rdzv)
+            rec.update(dt=dt, st=st, true_res=true_res, self_check=check, failures=failures, rccl_init_s=st.get("t_comm_init", 0.0))
+            default_label = RANK_LABELS.get(default_exchange, str(default_exchange))
+            modes = {"default": default_label, default_label: mode_record(args.steps, dt, st, true_res)}
+
+            def timed(label, **opts):
+                for k_, v_ in opts.items():
+                    s.set_option(k_, v_)
+                s.cg_init()
+                if args.warmup > 0:
+                    s.cg_iterate(args.warmup, 0.0)
+                barrier()
+                t0_ = time.perf_counter()
+                st_ = s.cg_iterate(args.steps, 0.0)
+                barrier()
+                dt_, st_ = max_over_ranks(time.perf_counter() - t0_, st_)
+                modes[label] = mode_record(args.steps, dt_, st_, s.true_residual())
+
+            if world > 1 or os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0"):
+                # Same problem, same context, the other exchanges of the rank mode (all product paths under the same parity
+                # tests) -- recorded for comparison, never the headline.
+                if default_exchange == 0:
+                    timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0)
+                else:
+                    timed("allgather_x2+allgather_p", exchange=0, overlap=1)
+                if default_exchange != 1:
+                    timed("allgather_Ap", exchange=1, overlap=1)
+                # the opt-in symmetric product on row shards (every pair {i, j} read once, cyclic half windows; each rank gathers the
+                # others' full-length contributions): a different algorithm, never the headline
+                sym_label = "allgather_Ap + symmetric product (option, not the headline)"
+                try:
+                    s.set_option("exchange", 1)
+                    s.set_option("symmetric", 1)
+                    if s.get_option("symmetric_effective") != 1:       # the same answer on every rank (it depends on N and the rank count only)
+                        modes[sym_label] = {"error": "option not effective for this configuration"}
+                    else:
+                        timed(sym_label, exchange=1, overlap=1, symmetric=1)
+                except Exception as e:   # noqa: BLE001  -- recorded, never fatal for the headline
+                    modes[sym_label] = {"error": str(e)[:300]}
+                finally:
+                    s.set_option("symmetric", 0)
+                s.set_option("exchange", default_exchange)
+                s.set_option("overlap", 1)
+            rec["exchange_modes"] = modes
+        else:
+            # The direct exchange (peer-mapped mailboxes, no collective call inside the iteration; EXPERIMENTAL until it has run on
+            # real peers).  Every step ends with an agreement over the control plane, so all ranks take the same path: a rank that
+            # cannot map its peers (all ranks then fall back to exchange 0) or a bounded wait that expires ends the attempt on ALL
+            # ranks, and nothing collective on the device follows it.
+            modes = {}
+            s.generate_random_spd(n, 1234, 1e6)
+            s.generate_random_rhs(1235)
+
+            def agree(ok_):
+                return all(x == b"1" for x in rdzv.allgather(b"1" if ok_ else b"0"))
+
+            def attempt(fn):
+                try:
+                    return True, fn(), None
+                except Exception as e:   # noqa: BLE001
+                    return False, None, str(e)[:300]
+
+            def init_direct(overlap):
+                s.set_option("exchange", 2)
+                s.set_option("overlap", overlap)
+                s.cg_init()
+                if s.get_option("exchange_effective") != 2:
+                    raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
+
+            def try_direct(label, overlap):
+                """One timed run on the direct exchange; records it under `label`; True if it produced a number."""
+                ok_, _, err_ = attempt(lambda: init_direct(overlap))
+                if not agree(ok_):
+                    modes[label] = {"error": err_ or "another rank could not set up the direct exchange"}
+                    return False
+                maybe_die(leg_name, "init")
+                ok_, _, err_ = attempt(lambda: s.cg_iterate(args.warmup, 0.0) if args.warmup > 0 else None)
+                if not agree(ok_):                          # doubles as the barrier in front of the timed region
+                    modes[label] = {"error": err_ or "another rank failed in the warm-up"}
+                    return False
+                maybe_die(leg_name, "timed")
+                t0_ = time.perf_counter()
+                ok_, st_, err_ = attempt(lambda: s.cg_iterate(args.steps, 0.0))
+                all_ok_ = agree(ok_)                        # doubles as the closing barrier
+                dt_ = time.perf_counter() - t0_
+                if not all_ok_:
+                    modes[label] = {"error": err_ or "another rank failed in the timed iterations"}
+                    return False
+                dt_, st_ = max_over_ranks(dt_, st_)
+                res_ = s.true_residual()
+                modes[label] = mode_record(args.steps, dt_, st_, res_, experimental=True)
+                if not abs(res_ / st_["rel_err"] - 1) < 1e-6:
+                    modes[label]["error"] = "recomputed residual differs from the recursive one: WRONG RESULT on this hardware"
+                return True
+
+            if try_direct("direct_mailboxes", 1):
+                try_direct("direct_mailboxes, no split", 0)
+            rec["exchange_modes"] = modes
+        rec["rccl_calls_enqueued"] = s.get_option("collectives_enqueued")
+        return rec
+    finally:
+        s.close()
+
+
+def one_process_measure(lam, args, n_gpus, part, leg_name=None):
+    """ONE process driving all shards (the reference's ConjugateGradient_MultiGPUS_CUDA topology).  part = "main": the default
+    exchange (gather-Ap) + every other product exchange of this topology + the symmetric option, each with the residual check
+    against the one-GPU solve and the host time it takes to enqueue an iteration; part = "direct": the EXPERIMENTAL in-kernel flag
+    exchange only."""
+    n = args.n
+    # LAM_BENCH_DEVICE_IDS="0,0" (tests on a one-GPU box): put the shards of the one-process topology on these devices
+    dev_override = [int(x) for x in os.environ.get("LAM_BENCH_DEVICE_IDS", "").split(",") if x.strip() != ""]
+    device_ids = dev_override if len(dev_override) == n_gpus else list(range(n_gpus))
+    s = lam.Solver(lam.F64, n_shards=n_gpus, device_ids=device_ids)
+    try:
+        s.set_option("gemv_timing", args.gemv_timing)
+        rec = {"n_gpus": n_gpus, "parallelism": f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores ordered by HIP events", "device_ids": device_ids}
+        default_exchange, default_join = s.get_option("exchange"), s.get_option("exchange_join")
+
+        def nobarrier():
+            pass
+
+        if part == "main":
+            host_ns0 = s.get_option("host_enqueue_ns")
+            st, dt = run_config(s, n, args.warmup, args.steps, nobarrier, ramp_s=args.ramp if leg_name is None else min(args.ramp, 0.3))
+            rec["kernel"] = s.gemv_kernel_name()
+            rec["cold_start"] = run_config.cold
+            effective = s.get_option("exchange_effective")
+            rec["exchange_effective"] = effective
+            host_us = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
+            rec["host_enqueue_us_per_step"] = host_us
+            true_res = s.true_residual()
+            check, failures = self_check(lam, args, n_gpus, st, true_res, 0, None)
+            rec.update(dt=dt, st=st, true_res=true_res, self_check=check, failures=failures)
+            eff_label = LOCAL_LABELS.get(effective, str(effective))
+            if effective == 1:
+                eff_label += ", join through shard 0" if default_join else ", all-to-all join"
+            ref_err = check.get("one_gpu_reference_residual")
+
+            def vs_ref(err_):
+                return abs(err_ / ref_err - 1) if ref_err else None
+
+            modes = {"default": eff_label,
+                     eff_label: mode_record(args.steps, dt, st, true_res, host_enqueue_us_per_step=host_us, vs_one_gpu=vs_ref(st["rel_err"]))}
+            rec["exchange_modes"] = modes
+            timed_local = make_timed_local(s, args, modes, vs_ref)
+            timed_local(LOCAL_LABELS[1] + ", join through shard 0", exchange=1, exchange_join=1)
+            timed_local(LOCAL_LABELS[1] + ", all-to-all join", exchange=1, exchange_join=0)
+            timed_local(LOCAL_LABELS[0], exchange=0)
+            # the opt-in symmetric product on row shards (cyclic half windows, every shard contributes a full-length vector per
+            # iteration): a different algorithm -- other rounding, hence the wider gate against the one-GPU solve --, never the headline
+            try:
+                timed_local(LOCAL_LABELS[1] + " + symmetric product (option, not the headline)", tol_vs=1e-6, exchange=1, exchange_join=default_join, symmetric=1)
+            finally:
+                s.set_option("symmetric", 0)
+            try:
+                s.set_option("exchange", default_exchange)
+                s.set_option("exchange_join", default_join)
+                s.set_option("overlap", 1)
+            except Exception:   # noqa: BLE001
+                pass
+        else:
+            modes = {}
+            rec["exchange_modes"] = modes
+            s.generate_random_spd(n, 1234, 1e6)
+            s.generate_random_rhs(1235)
+            ref_err = None
+            try:        # this leg's own one-GPU reference: its residual gate does not depend on the parent
+                ref_err = one_gpu_reference(lam, n, args.warmup + args.steps, device_ids[0])
+            except Exception as e:   # noqa: BLE001
+                rec["one_gpu_reference_error"] = str(e)[:300]
+
+            def vs_ref(err_):
+                return abs(err_ / ref_err - 1) if ref_err else None
+
+            timed_local = make_timed_local(s, args, modes, vs_ref, leg_name=leg_name)
+            # an expired in-kernel wait leaves the context unusable (the error is recorded)
+            timed_local(LOCAL_LABELS[2] + ", own-slice panel first", experimental=True, exchange=2, overlap=1)
+            if "error" not in modes[LOCAL_LABELS[2] + ", own-slice panel first"]:
+                timed_local(LOCAL_LABELS[2] + ", no split", experimental=True, exchange=2, overlap=0)
+        return rec
+    finally:
+        s.close()
+
+
+def make_timed_local(s, args, modes, vs_ref, leg_name=None):
+    def timed_local(label, experimental=False, tol_vs=1e-9, **opts):
+        if label in modes:
+            return
+        try:
+            for k_, v_ in opts.items():
+                s.set_option(k_, v_)
+            s.cg_init()
+            want = opts.get("exchange")
+            if want is not None and s.get_option("exchange_effective") != want:
+                raise RuntimeError(f"exchange {want} is not available for this configuration (shared devices, peer mappings)")
+            if opts.get("symmetric") and s.get_option("symmetric_effective") != 1:
+                raise RuntimeError("option symmetric is not effective for this configuration")
+            if experimental:
+                maybe_die(leg_name, "init")
+            if args.warmup > 0:
+                s.cg_iterate(args.warmup, 0.0)
+            if experimental:
+                maybe_die(leg_name, "timed")
+            h0_ = s.get_option("host_enqueue_ns")
+            t0_ = time.perf_counter()
+            st_ = s.cg_iterate(args.steps, 0.0)
+            dt_ = time.perf_counter() - t0_
+            h1_ = s.get_option("host_enqueue_ns")
+            res_ = s.true_residual()
+            rec = mode_record(args.steps, dt_, st_, res_, host_enqueue_us_per_step=(h1_ - h0_) / args.steps * 1e-3, vs_one_gpu=vs_ref(st_["rel_err"]))
+            if experimental:
+                rec["experimental"] = True
+            if not (abs(res_ / st_["rel_err"] - 1) < 1e-6 and (rec["vs_one_gpu"] is None or rec["vs_one_gpu"] < tol_vs)):
+                rec["error"] = "residual differs from the one-GPU solve: WRONG RESULT on this hardware"
+            modes[label] = rec
+        except Exception as e:   # noqa: BLE001
+            modes[label] = {"error": str(e)[:300]}
+    return timed_local
+
+
+def public(rec):
+    """A topology record as it goes into the JSON line (the raw stats and timers stay inside)."""
+    if rec is None:
+        return None
+    out = {k: v for k, v in rec.items() if k not in ("dt", "st", "true_res", "failures", "cold_start")}
+    if "st" in rec:
+        st, dt = rec["st"], rec["dt"]
+        steps = rec.get("steps")
+        out.update(mode_record(steps, dt, st, rec["true_res"]) if steps else {})
+        if rec.get("failures"):
+            out["error"] = "; ".join(rec["failures"])
+            out["value_unchecked"], out["value"] = out.get("value"), None
+    return out
+
+
+def leg_main(args):
+    """Child-process mode: run one leg and leave its record in --leg-out (rank 0 of the leg writes it)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.dup2(2, 1)                      # nothing of a leg goes to the caller's stdout
+    lam = importlib.import_module(PKG)
+    lam.lib()
+    leg = args.leg
+    n_gpus = max(1, args.gpus)
+    rdzv = lam.Rendezvous() if leg.startswith("rank") else None
+    try:
+        if leg == "rank_mode":
+            rec = rank_mode_measure(lam, args, rdzv, "main", leg_name=leg)
+        elif leg == "rank_direct":
+            rec = rank_mode_measure(lam, args, rdzv, "direct", leg_name=leg)
+        elif leg == "one_process":
+            rec = one_process_measure(lam, args, n_gpus, "main", leg_name=leg)
+        elif leg == "one_direct":
+            rec = one_process_measure(lam, args, n_gpus, "direct", leg_name=leg)
+        else:
+            raise SystemExit(f"unknown leg '{leg}'")
+        rec["steps"] = args.steps
+        if rdzv is None or rdzv.rank == 0:
+            write_leg_record(args.leg_out, public(rec))
+    finally:
+        if rdzv is not None:
+            try:
+                rdzv.barrier()
+            except Exception:   # noqa: BLE001
+                pass
+            rdzv.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,17 +720,23 @@ def main():
                     help="(1 GPU) use the upper-triangle product instead of the general GEMV; never the headline")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 PMC passes (roofline.traffic then "
                     "comes from profiles/traffic.json, tagged as such)")
-    ap.add_argument("--gemv-timing", type=int, default=4, help="time the GEMV of every T-th iteration with a HIP-event pair")
+    ap.add_argument("--no-legs", action="store_true", help="N > 1: do not start the child-process legs (the other topology, the experimental exchange)")
+    ap.add_argument("--gemv-timing", type=int, default=4, help="time the GEMV (and the exchange) of every T-th iteration with HIP-event pairs")
     ap.add_argument("--ramp", type=float, default=0.6, help="seconds of untimed GEMV launches before the warm-up steps of the headline "
                     "(waits out the driver's wipe of VRAM released by the child processes, see settle); 0 = none")
     ap.add_argument("--config4-n", type=int, default=131072, help="matrix order of the configs[3] GEMV-only side run")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="matrix order of the CPU baseline sample (0 = the workload's own N: "
                     "no extrapolation; the reference driver needs 8*N^2 bytes of host memory)")
     ap.add_argument("--cpu-sample-iters", type=int, default=20)
+    ap.add_argument("--leg-timeout", type=float, default=240.0, help="seconds a child-process leg may take")
     ap.add_argument("--mfma-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--leg-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.mfma_child:
         return mfma_child(args.config4_n)
+    if args.leg:
+        return leg_main(args)
 
     # stdout carries ONE line, the JSON: native libraries print there too (RCCL writes a five-line version banner to
     # stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON
@@ -290,15 +754,16 @@ def main():
     lam = importlib.import_module(PKG)
     lam.lib()
     use_dist = lam.launched_with_ranks()
-    rdzv = lam.Rendezvous() if use_dist else None
+    rdzv = lam.Rendezvous(timeout=max(180.0, 3 * args.leg_timeout + 60.0)) if use_dist else None
     world = rdzv.size if rdzv else 1
     rank = rdzv.rank if rdzv else 0
     profiled = under_profiler()
-    solo = rank == 0 and not use_dist and max(1, args.gpus) == 1
+    n_gpus = world if use_dist else max(1, args.gpus)
+    solo = rank == 0 and not use_dist and n_gpus == 1
+    n = args.n
 
-    # The one child process (the CPU baseline) goes FIRST: nothing has touched the GPU yet (a process that
-    # has initialised the GPU must not fork+exec on this pool), and never under a profiler (its tool
-    # library initialises the GPU before main()).
+    # Children go FIRST: nothing has touched the GPU yet (a process that has initialised the GPU must not fork+exec on this
+    # pool), and never under a profiler (its tool library initialises the GPU before main()).
     cb, mfma_rows = None, None
     if solo and not args.no_also and not profiled and not args.symmetric:
         mfma_rows = run_mfma_child(args.config4_n)      # first: its 34 GB are wiped while the CPU baseline runs
@@ -310,269 +775,101 @@ def main():
         if live_traffic[0] is None:
             sys.stderr.write(f"[bench] live PMC traffic measurement not available: {live_traffic[1]}\n")
 
+    # N > 1: the legs (see the module docstring).  `other` = the topology this process is NOT; `direct_*` = the EXPERIMENTAL
+    # exchange of either topology, each in processes of its own.
+    legs = {}
+    forced_rccl = use_dist and os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0")     # a 1-rank communicator (tests on one GPU)
+    want_legs = (n_gpus > 1 or forced_rccl) and not args.no_legs and not profiled and not args.symmetric
+    want_direct = want_legs and os.environ.get("LAM_BENCH_DIRECT", "1") != "0"
+    if want_legs and not use_dist:
+        def rank_env(i):
+            return {"RANK": str(i), "WORLD_SIZE": str(n_gpus), "LOCAL_RANK": str(i)}
+        legs["rank_mode"] = run_leg(args, "rank_mode", n_gpus, args.leg_timeout, rank_env=rank_env)
+        if want_direct:
+            legs["rank_direct"] = run_leg(args, "rank_direct", n_gpus, args.leg_timeout, rank_env=rank_env)
+            legs["one_direct"] = run_leg(args, "one_direct", 1, args.leg_timeout)
+    if want_legs and use_dist:
+        # rank 0 alone runs the one-process topology (the other ranks hold no GPU state yet and wait at the barrier below);
+        # the direct exchange of the rank mode needs a fresh process PER RANK: every rank starts its own child, and the children
+        # find each other through a rendezvous file of their own
+        if rank == 0 and n_gpus > 1:
+            legs["one_process"] = run_leg(args, "one_process", 1, args.leg_timeout)
+            if want_direct:
+                legs["one_direct"] = run_leg(args, "one_direct", 1, args.leg_timeout)
+        token = rdzv.broadcast(os.urandom(8).hex().encode() if rank == 0 else b"").decode()
+        if want_direct:
+            my_env = {"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rdzv.local_rank)}
+            rec = run_leg(args, "rank_direct", 1, args.leg_timeout, rank_env=lambda i: my_env, rdzv_file=f"/tmp/lam_rdzv.leg.{token}",
+                          expect_record=rank == 0)      # the leg's rank 0 writes the record
+            errs = [e.decode() for e in rdzv.allgather((rec.get("error") or "").encode())]
+            if rank == 0:
+                others = "; ".join(f"rank {q}: {e}" for q, e in enumerate(errs) if e and q != 0)
+                if others:
+                    rec["error"] = (rec.get("error", "") + "; " if rec.get("error") else "") + others[:600]
+                legs["rank_direct"] = rec
+        rdzv.barrier()
+
+    # ---- this process's own topology ------------------------------------------------------------------------------------
+    exchange_modes, effective_exchange, rccl_info = None, None, None
     if use_dist:
-        uid = rdzv.broadcast(lam.get_unique_id() if rank == 0 else b"")
-        ndev = lam.device_count()          # counting devices does not initialise the GPU
-
-        def make_solver():
-            return lam.Solver(lam.F64, rank=rank, nranks=world, device_id=rdzv.local_rank % max(1, ndev), unique_id=uid)
-
-        barrier = rdzv.barrier
-        n_gpus = world
-        parallelism = f"row-sharded x{world}, 1 process/GPU, RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration"
+        rec = rank_mode_measure(lam, args, rdzv, "main")
+        st, dt, true_res, check, failures = rec["st"], rec["dt"], rec["true_res"], rec["self_check"], rec["failures"]
+        kernel_name, cold_start, parallelism = rec["kernel"], rec["cold_start"], rec["parallelism"]
+        host_us_per_step, effective_exchange = rec["host_enqueue_us_per_step"], rec["exchange_effective"]
+        exchange_modes = rec["exchange_modes"] if world > 1 or forced_rccl else None
+        rccl_info = {"rccl_version": rec["rccl_version"], "rccl_ranks": rec["rccl_ranks"], "rccl_calls_enqueued_rank0": rec["rccl_calls_enqueued"]}
+        s = None
+    elif n_gpus > 1:
+        rec = one_process_measure(lam, args, n_gpus, "main")
+        st, dt, true_res, check, failures = rec["st"], rec["dt"], rec["true_res"], rec["self_check"], rec["failures"]
+        kernel_name, cold_start, parallelism = rec["kernel"], rec["cold_start"], rec["parallelism"]
+        host_us_per_step, effective_exchange = rec["host_enqueue_us_per_step"], rec["exchange_effective"]
+        exchange_modes = rec["exchange_modes"]
+        s = None
     else:
-        n_gpus = max(1, args.gpus)
-        # LAM_BENCH_DEVICE_IDS="0,0" (tests on a one-GPU box): put the shards of the one-process topology on these devices
-        dev_override = [int(x) for x in os.environ.get("LAM_BENCH_DEVICE_IDS", "").split(",") if x.strip() != ""]
-        device_ids = dev_override if len(dev_override) == n_gpus else list(range(n_gpus))
-
-        def make_solver():
-            if n_gpus == 1:
-                return lam.Solver(lam.F64)
-            return lam.Solver(lam.F64, n_shards=n_gpus, device_ids=device_ids)
+        s = lam.Solver(lam.F64)
+        # t_gemv (roofline.achieved) = average of HIP-event pairs around the GEMV launch of every 4th iteration of the timed steps
+        # (library default: every 8th; each record is a marker packet in the stream, ~2 us per iteration at this rate)
+        s.set_option("gemv_timing", args.gemv_timing)
+        host_ns0 = s.get_option("host_enqueue_ns")
 
         def barrier():
             pass
-        parallelism = "1 GPU" if n_gpus == 1 else f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores ordered by HIP events"
+        st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric, ramp_s=args.ramp)
+        kernel_name = s.gemv_kernel_name()
+        cold_start = run_config.cold
+        parallelism = "1 GPU"
+        # host time the library spent issuing one iteration of the headline configuration (its waits for the device excluded)
+        host_us_per_step = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
+        true_res = s.true_residual()
+        check, failures = self_check(lam, args, 1, st, true_res, 0, None, symmetric=args.symmetric)
 
-    n = args.n
-    s = make_solver()
-    # t_gemv (roofline.achieved) = average of HIP-event pairs around the GEMV launch of every 4th iteration of the timed steps
-    # (library default: every 8th; each record is a marker packet in the stream, ~2 us per iteration at this rate)
-    s.set_option("gemv_timing", args.gemv_timing)
-    # HEADLINE = the product's default configuration of this topology (rank mode: lam_hip's default exchange), whatever
-    # the other exchange modes measure below; they are recorded under "exchange_modes" only.
-    default_exchange = s.get_option("exchange") if (use_dist or n_gpus > 1) else None
-    default_join = s.get_option("exchange_join") if n_gpus > 1 and not use_dist else None
-    host_ns0 = s.get_option("host_enqueue_ns")
-    st, dt = run_config(s, n, args.warmup, args.steps, barrier, symmetric=args.symmetric, ramp_s=args.ramp)
-    kernel_name = s.gemv_kernel_name()
-    cold_start = run_config.cold
-    effective_exchange = s.get_option("exchange_effective") if default_exchange is not None else None
-    # host time the library spent issuing one iteration of the headline configuration (its waits for the device excluded)
-    host_us_per_step = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
+    # merge the experimental legs into the exchange modes of the topology they belong to, checked against that topology's residual
+    def merge_direct(target_modes, leg_rec, target_res):
+        if target_modes is None or leg_rec is None:
+            return
+        got = leg_rec.get("exchange_modes") or {}
+        for label, m in got.items():
+            if isinstance(m, dict) and "rel_residual_true" in m and target_res and not abs(m["rel_residual_true"] / target_res - 1) < 1e-6 and "error" not in m:
+                m["error"] = "residual differs from the default exchange: WRONG RESULT on this hardware"
+            target_modes[label] = m
+        if not got:
+            target_modes["direct (experimental leg)"] = {"error": leg_rec.get("error", "the leg produced no record"), "experimental": True}
+        elif leg_rec.get("error"):
+            target_modes["direct (experimental leg)"] = {"error": leg_rec["error"], "experimental": True}
 
-    def max_over_ranks(dt_, st_):
-        if rdzv is None:
-            return dt_, st_
-        dt_, st_["t_gemv"] = rdzv.max([dt_, st_["t_gemv"]])
-        return dt_, st_
-
-    dt, st = max_over_ranks(dt, st)
-    true_res = s.true_residual()
-
-    # Self-check of the headline (every GPU count): the recomputed true residual must equal the recursive one, and with
-    # more than one GPU the residual must agree with the SAME solve on one GPU (rank 0 runs it on its own device right
-    # here: N=65536 fits one MI355X).  A line that fails carries "value": null and the process exits non-zero.
-    check = {"true_vs_recursive": abs(true_res / st["rel_err"] - 1) if st["rel_err"] > 0 else float("inf"), "tolerance_true_vs_recursive": 1e-6}
-    failures = []
-    if not check["true_vs_recursive"] < 1e-6:
-        failures.append(f"true residual {true_res:.15e} != recursive residual {st['rel_err']:.15e}")
-    if n_gpus > 1 and not args.symmetric:
-        ref_err, ref_fail = None, None
-        if rank == 0:
-            try:
-                with lam.Solver(lam.F64, device_ids=[rdzv.local_rank % max(1, lam.device_count())] if rdzv else [0]) as ref:
-                    # LAM_BENCH_SELFTEST_FAIL=1 (tests only): the reference solves a DIFFERENT system, so the check must fail
-                    ref.generate_random_spd(n, 1234 + (1 if os.environ.get("LAM_BENCH_SELFTEST_FAIL") else 0), 1e6)
-                    ref.generate_random_rhs(1235)
-                    ref.cg_init()
-                    ref_err = ref.cg_iterate(args.warmup + args.steps, 0.0)["rel_err"]
-            except Exception as e:   # noqa: BLE001
-                ref_fail = f"one-GPU reference solve failed: {e}"[:300]
-        if rank == 0:
-            check["one_gpu_reference_residual"] = ref_err
-            check["tolerance_vs_one_gpu"] = 1e-9
-            if ref_err is None:
-                failures.append(ref_fail or "no one-GPU reference")
-            else:
-                check["vs_one_gpu"] = abs(st["rel_err"] / ref_err - 1)
-                if not check["vs_one_gpu"] < 1e-9:
-                    failures.append(f"residual after {args.warmup + args.steps} iterations {st['rel_err']:.15e} differs from the one-GPU solve {ref_err:.15e}")
-        if rdzv is not None:
-            rdzv.barrier()
-    check["passed"] = not failures
-    headline = {"dt": dt, "st": st, "true_res": true_res, "parallelism": parallelism}
-
-    exchange_modes = None
-    if rdzv is not None and (world > 1 or os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0")):
-        # Same problem, same context, the other exchanges of the rank mode (all product paths under the same parity
-        # tests) -- recorded for comparison, never the headline.
-        default_label = {0: "allgather_x2+allgather_p", 1: "allgather_Ap", 2: "direct_mailboxes"}.get(default_exchange, str(default_exchange))
-        exchange_modes = {"default": default_label,
-                          default_label: {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                                          "gemv_ms": st["t_gemv"] * 1e3, "rel_residual_true": true_res}}
-
-        def timed(label, **opts):
-            for k_, v_ in opts.items():
-                s.set_option(k_, v_)
-            s.cg_init()
-            if args.warmup > 0:
-                s.cg_iterate(args.warmup, 0.0)
-            barrier()
-            t0_ = time.perf_counter()
-            st_ = s.cg_iterate(args.steps, 0.0)
-            barrier()
-            dt_, st_ = max_over_ranks(time.perf_counter() - t0_, st_)
-            res_ = s.true_residual()
-            exchange_modes[label] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3,
-                                     "gemv_ms": st_["t_gemv"] * 1e3, "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
-
-        if default_exchange == 0:
-            timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0)
+    other_topology = None
+    if rank == 0 and (n_gpus > 1 or forced_rccl):
+        if use_dist:
+            merge_direct(exchange_modes, legs.get("rank_direct"), true_res)
+            other_topology = legs.get("one_process")
+            if other_topology is not None:
+                merge_direct(other_topology.setdefault("exchange_modes", {}), legs.get("one_direct"), other_topology.get("rel_residual_true"))
         else:
-            timed("allgather_x2+allgather_p", exchange=0, overlap=1)
-        if default_exchange != 1:
-            timed("allgather_Ap", exchange=1, overlap=1)
-        # the opt-in symmetric product on row shards (every pair {i, j} read once, cyclic half windows; each rank gathers the
-        # others' full-length contributions): a different algorithm, never the headline
-        sym_label = "allgather_Ap + symmetric product (option, not the headline)"
-        try:
-            s.set_option("exchange", 1)
-            s.set_option("symmetric", 1)
-            if s.get_option("symmetric_effective") != 1:       # the same answer on every rank (it depends on N and the rank count only)
-                exchange_modes[sym_label] = {"error": "option not effective for this configuration"}
-            else:
-                timed(sym_label, exchange=1, overlap=1, symmetric=1)
-        except Exception as e:   # noqa: BLE001  -- recorded, never fatal for the headline
-            exchange_modes[sym_label] = {"error": str(e)[:300]}
-        finally:
-            s.set_option("symmetric", 0)
-        # Before the experimental part: should anything below take the process down, the headline is on record.
-        if rank == 0:
-            sys.stderr.write("[bench] provisional (before the direct-exchange runs): " + json.dumps(
-                {"value": args.steps / dt if not failures else None, "n_gpus": n_gpus, "ms_per_step": dt / args.steps * 1e3,
-                 "gemv_ms": st["t_gemv"] * 1e3, "self_check": check, "exchange_modes": exchange_modes}) + "\n")
-            sys.stderr.flush()
-        # Last, because a failure here leaves the ranks' device state out of step: the direct exchange (peer-
-        # mapped mailboxes, no collective call inside the iteration; EXPERIMENTAL until it has run on real peers).
-        # Every step ends with an agreement over the control plane, so all ranks take the same path: a rank that
-        # cannot map its peers (all ranks then fall back to exchange 0) or a bounded wait that expires ends the
-        # attempt on ALL ranks, and nothing collective on the device follows it.
-        def agree(ok_):
-            return all(x == b"1" for x in rdzv.allgather(b"1" if ok_ else b"0"))
-
-        def attempt(fn):
-            try:
-                return True, fn(), None
-            except Exception as e:   # noqa: BLE001
-                return False, None, str(e)[:300]
-
-        def init_direct(overlap):
-            s.set_option("exchange", 2)
-            s.set_option("overlap", overlap)
-            s.cg_init()
-            if s.get_option("exchange_effective") != 2:
-                raise RuntimeError("peer mappings not available: fell back to the RCCL exchange")
-
-        def try_direct(label, overlap):
-            """One timed run on the direct exchange; records it under `label`; True if it produced a number."""
-            if os.environ.get("LAM_BENCH_DIRECT", "1") == "0":
-                exchange_modes[label] = {"error": "skipped (LAM_BENCH_DIRECT=0)"}
-                return False
-            ok_, _, err_ = attempt(lambda: init_direct(overlap))
-            if not agree(ok_):
-                exchange_modes[label] = {"error": err_ or "another rank could not set up the direct exchange"}
-                return False
-            ok_, _, err_ = attempt(lambda: s.cg_iterate(args.warmup, 0.0) if args.warmup > 0 else None)
-            if not agree(ok_):                          # doubles as the barrier in front of the timed region
-                exchange_modes[label] = {"error": err_ or "another rank failed in the warm-up"}
-                return False
-            t0_ = time.perf_counter()
-            ok_, st_, err_ = attempt(lambda: s.cg_iterate(args.steps, 0.0))
-            all_ok_ = agree(ok_)                        # doubles as the closing barrier
-            dt_ = time.perf_counter() - t0_
-            if not all_ok_:
-                exchange_modes[label] = {"error": err_ or "another rank failed in the timed iterations"}
-                return False
-            dt_, st_ = max_over_ranks(dt_, st_)
-            res_ = s.true_residual()
-            exchange_modes[label] = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
-                                     "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"], "experimental": True}
-            # it solved the same problem only if its residual matches the default exchange's (all exchanges are
-            # deterministic and agree to rounding) and the recomputed residual matches the recursive one
-            if not (abs(res_ / st_["rel_err"] - 1) < 1e-6 and abs(res_ / true_res - 1) < 1e-6):
-                exchange_modes[label]["error"] = "residual differs from the default exchange: WRONG RESULT on this hardware"
-            return True
-
-        if default_exchange != 2 and try_direct("direct_mailboxes", 1):
-            try_direct("direct_mailboxes, no split", 0)
-        s.set_option("exchange", default_exchange)
-        s.set_option("overlap", 1)
-    if rdzv is None and n_gpus > 1 and not args.symmetric:
-        # ONE process driving all shards (the reference's ConjugateGradient_MultiGPUS_CUDA topology): the same problem on
-        # the same context with every exchange of this topology -- recorded for comparison, never the headline, each with
-        # the residual check against the one-GPU solve and the host time it takes to enqueue an iteration.
-        labels = {0: "events_x3 (p.Ap, r.r, p slices: three joins per iteration)", 1: "gather_Ap (one join per iteration)", 2: "direct_flags"}
-        eff_label = labels.get(effective_exchange, str(effective_exchange))
-        if effective_exchange == 1:
-            eff_label += ", join through shard 0" if default_join else ", all-to-all join"
-        ref_err = check.get("one_gpu_reference_residual")
-
-        def vs_ref(err_):
-            return abs(err_ / ref_err - 1) if ref_err else None
-
-        exchange_modes = {"default": eff_label,
-                          eff_label: {"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "gemv_ms": st["t_gemv"] * 1e3,
-                                      "host_enqueue_us_per_step": host_us_per_step, "rel_residual_true": true_res, "rel_residual_recursive": st["rel_err"], "vs_one_gpu": vs_ref(st["rel_err"])}}
-
-        def timed_local(label, experimental=False, tol_vs=1e-9, **opts):
-            if label in exchange_modes:
-                return
-            try:
-                for k_, v_ in opts.items():
-                    s.set_option(k_, v_)
-                s.cg_init()
-                want = opts.get("exchange")
-                if want is not None and s.get_option("exchange_effective") != want:
-                    raise RuntimeError(f"exchange {want} is not available for this configuration (N % shards, shared devices, peer mappings)")
-                if opts.get("symmetric") and s.get_option("symmetric_effective") != 1:
-                    raise RuntimeError("option symmetric is not effective for this configuration")
-                if args.warmup > 0:
-                    s.cg_iterate(args.warmup, 0.0)
-                h0_ = s.get_option("host_enqueue_ns")
-                t0_ = time.perf_counter()
-                st_ = s.cg_iterate(args.steps, 0.0)
-                dt_ = time.perf_counter() - t0_
-                h1_ = s.get_option("host_enqueue_ns")
-                res_ = s.true_residual()
-                rec = {"value": args.steps / dt_, "ms_per_step": dt_ / args.steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3,
-                       "host_enqueue_us_per_step": (h1_ - h0_) / args.steps * 1e-3, "rel_residual_true": res_,
-                       "rel_residual_recursive": st_["rel_err"], "vs_one_gpu": vs_ref(st_["rel_err"])}
-                if experimental:
-                    rec["experimental"] = True
-                if not (abs(res_ / st_["rel_err"] - 1) < 1e-6 and (rec["vs_one_gpu"] is None or rec["vs_one_gpu"] < tol_vs)):
-                    rec["error"] = "residual differs from the one-GPU solve: WRONG RESULT on this hardware"
-                exchange_modes[label] = rec
-            except Exception as e:   # noqa: BLE001
-                exchange_modes[label] = {"error": str(e)[:300]}
-
-        timed_local(labels[1] + ", join through shard 0", exchange=1, exchange_join=1)
-        timed_local(labels[1] + ", all-to-all join", exchange=1, exchange_join=0)
-        timed_local(labels[0], exchange=0)
-        # the opt-in symmetric product on row shards (cyclic half windows, every shard contributes a full-length vector per
-        # iteration): a different algorithm -- other rounding, hence the wider gate against the one-GPU solve --, never the headline
-        try:
-            timed_local(labels[1] + " + symmetric product (option, not the headline)", tol_vs=1e-6, exchange=1, exchange_join=default_join, symmetric=1)
-        finally:
-            s.set_option("symmetric", 0)
-        sys.stderr.write("[bench] provisional (before the in-kernel flag exchange runs): " + json.dumps(
-            {"value": args.steps / dt if not failures else None, "n_gpus": n_gpus, "ms_per_step": dt / args.steps * 1e3,
-             "self_check": check, "exchange_modes": exchange_modes}) + "\n")
-        sys.stderr.flush()
-        if os.environ.get("LAM_BENCH_DIRECT", "1") != "0":
-            # last: an expired in-kernel wait leaves the context unusable (the error is recorded, the headline stands)
-            timed_local(labels[2] + ", own-slice panel first", experimental=True, exchange=2, overlap=1)
-            if "error" not in exchange_modes[labels[2] + ", own-slice panel first"]:
-                timed_local(labels[2] + ", no split", experimental=True, exchange=2, overlap=0)
-        try:
-            s.set_option("exchange", default_exchange)
-            s.set_option("exchange_join", default_join)
-            s.set_option("overlap", 1)
-        except Exception:   # noqa: BLE001
-            pass
-    dt, st, true_res, parallelism = headline["dt"], headline["st"], headline["true_res"], headline["parallelism"]
-    n_coll = s.get_option("collectives_enqueued")
+            merge_direct(exchange_modes, legs.get("one_direct"), true_res)
+            other_topology = legs.get("rank_mode")
+            if other_topology is not None:
+                merge_direct(other_topology.setdefault("exchange_modes", {}), legs.get("rank_direct"), other_topology.get("rel_residual_true"))
 
     # Side measurements, same process, same context, AFTER the headline (N=1 only, not under a profiler):
     # the opt-in symmetric product on the same system, then configs[1] (N=32768) and the sizes the reference
@@ -580,6 +877,8 @@ def main():
     also, sym = None, None
     keep_alive = []
     if solo and not args.no_also and not profiled and not args.symmetric:
+        def barrier():
+            pass
         try:
             st_s, dt_s = run_config(s, n, args.warmup, args.steps, barrier, symmetric=True, generate=False)
             sym = {"what": "lam_hip_set_option('symmetric', 1): the product reads only the upper triangle of the SPD matrix "
@@ -663,7 +962,8 @@ def main():
             config4.extend(mfma_rows)
     for ctx in keep_alive:
         ctx.close()
-    s.close()
+    if s is not None:
+        s.close()
 
     ms_per_step = dt / args.steps * 1e3
     gemv_bytes = st["gemv_bytes"]                 # algorithmic bytes of ONE launch on one GPU
@@ -688,6 +988,7 @@ def main():
                                     "`value_cold` is the same measurement without it -- rounds 1-2 and BASELINE-style figures are cold)",
                    "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
         "gemv_ms": st["t_gemv"] * 1e3,
+        **({"exchange_us": st["t_exchange"] * 1e6, "gemv_plus_comm_ms": (st["t_gemv"] + st["t_exchange"]) * 1e3} if n_gpus > 1 or use_dist else {}),
         **({"exchange_effective": effective_exchange} if effective_exchange is not None else {}),
         "other_us": (ms_per_step - st["t_gemv"] * 1e3) * 1e3,
         "host_enqueue_us_per_step": host_us_per_step,
@@ -704,10 +1005,15 @@ def main():
                      "algorithmic_bytes_per_launch": gemv_bytes},
         "host_plumbing": {"torch_imported": "torch" in sys.modules,
                           "rendezvous": "package socket rendezvous (_rendezvous.py)" if rdzv else None,
-                          "rccl_version": lam.rccl_version() if rdzv else None,
-                          "rccl_calls_enqueued_rank0": n_coll if rdzv else None,
+                          "rccl_version": rccl_info["rccl_version"] if rccl_info else None,
+                          "rccl_ranks": rccl_info["rccl_ranks"] if rccl_info else None,
+                          "rccl_calls_enqueued_rank0": rccl_info["rccl_calls_enqueued_rank0"] if rccl_info else None,
                           "profiler_detected": profiled},
     }
+    if n_gpus > 1 and rank == 0:
+        # the topology this process is not, measured by child processes in front of the headline (None: legs were switched off)
+        key = "one_process_topology" if use_dist else "rank_mode_rccl"
+        out[key] = other_topology if other_topology is not None else ({"skipped": "--no-legs, a profiler, or --symmetric"} if not want_legs else {"error": "leg not run"})
 
     if also:
         out["also"] = also

@@ -34,8 +34,17 @@
 extern "C" {
 #endif
 
-/* 2 (round 4): lam_hip_build_id (added in round 3 without a bump) and lam_hip_generate_spectrum_spd; nothing removed or changed */
-#define LAM_HIP_ABI_VERSION 3
+/* ABI history (a caller compares lam_hip_abi_version() with the LAM_HIP_ABI_VERSION it was compiled against):
+ *   1  rounds 1-3.
+ *   2  + lam_hip_build_id, lam_hip_generate_spectrum_spd.
+ *   3  + lam_hip_debug_symv_plan; BEHAVIOUR: lam_hip_create with more than one shard defaults to the gather-Ap exchange
+ *      (option "exchange" = 1; was 0), and option "symmetric" = 1 means "from 192 MiB of matrix on, any N, one or several
+ *      shards" (was: one shard, N a multiple of 4096).
+ *   4  (round 5) lam_hip_stats grows by t_exchange (appended: the older fields keep their offsets, but a caller must pass
+ *      the larger struct); BEHAVIOUR: the gather-Ap exchange takes any N >= shards (the reference's uneven partition), so
+ *      "exchange_effective" no longer drops to 0 for N % shards != 0; LAM_HIP_SYMMETRIC also selects exchange 1 in rank
+ *      mode when LAM_HIP_EXCHANGE is unset. */
+#define LAM_HIP_ABI_VERSION 4
 
 /* storage / arithmetic type of the matrix and vectors */
 #define LAM_HIP_F64 0  /* double everywhere (the reference drivers hard-code <double>) */
@@ -64,6 +73,13 @@ typedef struct lam_hip_stats {
     double t_total;       /* wall seconds of the call */
     double t_comm_init;   /* seconds spent creating the RCCL communicator (0 if none) */
     double gemv_bytes;    /* algorithmic bytes one GEMV launch on this rank reads+writes */
+    double t_exchange;    /* average seconds per iteration in the iteration's exchange step(s) on this rank / shard 0: the
+                           * RCCL collective(s), or the event join(s) of one process driving several shards (from the post
+                           * behind the producer kernel until the consumer's stream has passed its waits); sampled on the
+                           * iterations whose GEMV is timed (option "gemv_timing").  0 for one shard and for the direct
+                           * exchange (which waits inside its kernels).  t_gemv + t_exchange is what the reference prints
+                           * as its t_gemv column, which includes broadcast + gather
+                           * (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:352-377) */
 } lam_hip_stats;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */

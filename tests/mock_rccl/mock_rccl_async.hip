@@ -361,6 +361,9 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) { *count = reinterpret_cast<const Comm *>(comm)->w->nranks; return ncclSuccess; }
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) { *rank = reinterpret_cast<const Comm *>(comm)->rank; return ncclSuccess; }
+
 ncclResult_t ncclGroupStart() { return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { return ncclSuccess; }
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(lam):
 def test_binding_covers_header(lam):
     L = lam.lib()
     assert set(_declared_symbols()) == set(L._lam_symbols)
-    assert L.lam_hip_abi_version() == 3
+    assert L.lam_hip_abi_version() == 4
 
 
 def test_build_id_covers_every_source_of_the_translation_unit(lam):

@@ -304,6 +304,38 @@ def test_env_launched_driver_multi_rank(tmp_path, mock_mp_lib, golden, oracle, e
     assert not os.path.exists(tmp_path / "id")                          # rank 0 removed the rendezvous file
 
 
+def test_driver_csv_gemv_column_can_include_the_exchange(tmp_path, mock_mp_lib, golden):
+    """-g (or LAM_CSV_GEMV_PLUS_COMM=1 for drivers compiled from the reference's own sources): the CSV's GEMV column is
+    t_gemv + t_exchange -- the reference's convention, whose t_gemv brackets broadcast + kernel + gather
+    (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:352-377); without it the column is the GEMV kernel alone.  Two ranks, three ways:
+    plain, -g, and the environment variable; -v prints both numbers."""
+    g = next(x for x in golden["file_mode"] if x["n"] == 256)
+
+    def launch(extra_args, extra_env):
+        procs = []
+        for rank in range(2):
+            e = dict(os.environ, LD_PRELOAD=mock_mp_lib, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", LAM_RCCL_ID_FILE=str(tmp_path / "id"), **extra_env)
+            procs.append(subprocess.Popen([RCCL_EXE, "-A", os.path.join(GOLDEN, g["name"] + ".matrix.bin"), "-b", os.path.join(GOLDEN, g["name"] + ".rhs.bin"),
+                                           "-o", str(tmp_path / "sol.bin"), "-e", repr(g["tol"])] + extra_args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        try:
+            outs = [p.communicate(timeout=300) for p in procs]
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        assert all(p.returncode == 0 for p in procs), outs
+        return outs[0][0]
+
+    plain, plus, env = _csv(launch([], {})), _csv(launch(["-g"], {})), _csv(launch([], {"LAM_CSV_GEMV_PLUS_COMM": "1"}))
+    assert len(plain) == len(plus) == len(env) and plain[7] == plus[7] == env[7]           # same columns, same solve
+    assert 0 < float(plain[5]) and 0 < float(plus[5]) and 0 < float(env[5])
+    verbose = launch(["-v"], {})
+    import re
+    m = re.search(r"GEMV ([0-9.]+) ms = .* exchange ([0-9.]+) ms", verbose)
+    assert m and float(m.group(1)) > 0 and float(m.group(2)) >= 0, verbose      # (> 0 on the stream-ordered double: test_gpu_rank_mock.py)
+    # (the runs are separate solves, so the columns are compared through -v's two numbers: gemv + exchange > gemv)
+
+
 def test_rank_local_load_failure_fails_on_every_rank(tmp_path, mock_mp_lib, golden):
     """One rank cannot read the matrix: the loaders agree across ranks (lam_hip_all_ok), so EVERY rank
     leaves with exit code 1 instead of the others waiting in the first collective of the solve."""

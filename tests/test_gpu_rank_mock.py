@@ -113,6 +113,10 @@ def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, ov
     _check_solution(out, P, n, mode)
     if exchange == 1:
         assert out["exchange_effective"] == [1] * P, out      # any N >= P: no fallback (round 5)
+    # lam_hip_stats.t_exchange: the collectives of exchanges 0 / 1 are bracketed with HIP events on every rank (sampled with the
+    # GEMV timing); the direct exchange waits inside its kernels and reports none
+    if not (out["direct_fallbacks"][0] if exchange == 2 else 0):
+        assert all((t > 0) == (exchange != 2) for t in out["t_exchange"]) and all(t > 0 for t in out["t_gemv"]), out
     if exchange == 2:
         assert out["exchange_effective"] == [2] * P, out
         # set-up and the collective checks after the solve go through the communicator, the iterations do not
@@ -316,7 +320,9 @@ def test_direct_exchange_context_can_be_destroyed_right_after_iterating(mock_asy
 
 # ---- multi-process: the driver's exact torchrun command ------------------------------------------------
 def _bench_torchrun(mock, nproc, tmp_path, extra_env=None):
-    env = dict(os.environ, LD_PRELOAD=mock, GPU_MAX_HW_QUEUES="8", MOCK_RCCL_STATS_FILE=os.path.join(str(tmp_path), "st.jsonl"))
+    # LAM_BENCH_DEVICE_IDS / LAM_HIP_DIRECT_SAME_DEVICE: rank 0's one-process legs put all their shards on GPU 0 too
+    env = dict(os.environ, LD_PRELOAD=mock, GPU_MAX_HW_QUEUES=str(2 * nproc + 4), MOCK_RCCL_STATS_FILE=os.path.join(str(tmp_path), "st.jsonl"),
+               LAM_BENCH_DEVICE_IDS=",".join(["0"] * nproc), LAM_HIP_DIRECT_SAME_DEVICE="1")
     env.update(extra_env or {})
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     port = 29700 + nproc + os.getpid() % 100
@@ -353,6 +359,15 @@ def _check_bench_line(r, nproc):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
     assert abs(rf["algorithmic_bytes_per_launch"] - (8.0 * 8192 * 8192 / nproc + 8.0 * (8192 + 8192 / nproc))) < 1
     assert out["host_plumbing"]["torch_imported"] is False     # the N>1 path is torch-free
+    # round 5: RCCL names its ranks, every record times its exchange, and the OTHER topology (one process driving all shards) is
+    # on the same line, measured by a child of rank 0 before any rank touched the GPU -- its experimental exchange in a child of its own
+    assert out["host_plumbing"]["rccl_ranks"] == nproc and out["host_plumbing"]["rccl_calls_enqueued_rank0"] > 0
+    assert out["exchange_us"] > 0 and out["gemv_plus_comm_ms"] > out["gemv_ms"]
+    assert all(m["exchange_us"] > 0 for k, m in modes.items() if not k.startswith("direct")), modes
+    op = out["one_process_topology"]
+    assert "error" not in op and op["value"] > 0 and op["n_gpus"] == nproc and op["exchange_us"] > 0 and op["self_check"]["passed"], op
+    op_modes = {k: v for k, v in op["exchange_modes"].items() if k != "default"}
+    assert len(op_modes) == 6 and all("error" not in m and m["value"] > 0 for m in op_modes.values()), op_modes
     return out
 
 
@@ -374,7 +389,11 @@ def test_bench_torchrun_path_on_async_mock_across_processes(mock_async, tmp_path
         pytest.skip("HIP IPC between processes is not available on this box")
     _check_bench_line(r, nproc)
     lines = [json.loads(l) for l in open(os.path.join(str(tmp_path), "st.jsonl"))]
-    _check_mock_stats(lines, nproc)
+    # two communicators in this run: the experimental leg's (fresh processes, exchange 2 only) and the headline's -- each with one
+    # line per rank, nobody aborted, every rank of a communicator enqueued the same number of collectives
+    assert len(lines) == 2 * nproc and all(l["abort"] == 0 and l["err"] == 0 and l["host_abort"] == 0 for l in lines), lines
+    counts = sorted(l["calls"] for l in lines)
+    assert counts[:nproc] == [counts[0]] * nproc and counts[nproc:] == [counts[-1]] * nproc and counts[0] < counts[-1], counts
 
 
 @pytest.mark.parametrize("hook,expect", [
@@ -423,23 +442,21 @@ def test_bench_stdout_is_one_json_line_with_real_rccl(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
     out = json.loads(lines[0])
-    assert out["host_plumbing"]["rccl_version"] > 20000 and out["host_plumbing"]["torch_imported"] is False
+    assert out["host_plumbing"]["rccl_version"] > 20000 and out["host_plumbing"]["torch_imported"] is False and out["host_plumbing"]["rccl_ranks"] == 1
     assert set(out["exchange_modes"]) >= {"allgather_x2+allgather_p", "allgather_Ap", "direct_mailboxes"}
     vals = [m["rel_residual_true"] for m in out["exchange_modes"].values() if "rel_residual_true" in m]
     assert all(abs(v / vals[0] - 1) < 1e-6 for v in vals)
 
 
 @pytest.mark.parametrize("gpus", [2, 4])
-def test_bench_one_process_topology_records_every_exchange(tmp_path, gpus):
+def test_bench_one_process_topology_records_every_exchange(mock_async, tmp_path, gpus):
     """`python bench.py --gpus N` WITHOUT a launcher: one process drives N shards (the reference's single-process multi-GPU
     class, GPU/local/ConjugateGradient_MultiGPUS_CUDA.cu:326-409).  The line carries every exchange of that topology under
     exchange_modes -- gather-Ap with both joins, the three-join event exchange, the in-kernel flag exchange with and
     without the own-slice panel -- each with its residual check against the one-GPU solve and the host time per step;
     the headline is the library default (gather-Ap).  All shards on GPU 0 here (LAM_BENCH_DEVICE_IDS), one hardware
     queue per stream so that kernels of one shard can wait for kernels of another."""
-    env = dict(os.environ, LAM_BENCH_DEVICE_IDS=",".join(["0"] * gpus), GPU_MAX_HW_QUEUES=str(2 * gpus + 4), LAM_HIP_DIRECT_SAME_DEVICE="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LD_PRELOAD"):
-        env.pop(k, None)
+    env = _one_process_env(mock_async, gpus)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "3", "--order", "8192"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -458,3 +475,54 @@ def test_bench_one_process_topology_records_every_exchange(tmp_path, gpus):
     hosts = {k: v["host_enqueue_us_per_step"] for k, v in modes.items() if "host_enqueue_us_per_step" in v}
     assert len(hosts) == 6 and all(0 < h < 2000 for h in hosts.values()), hosts
     assert "1 process" in out["config"]["parallelism"]
+    # round 5: the SAME command also measured the rank mode -- `gpus` fresh processes on the RCCL exchange (here the stream-ordered
+    # double, all on GPU 0), started before the parent touched the GPU -- and every record times its exchange step
+    assert out["exchange_us"] > 0 and all(m["exchange_us"] > 0 for k, m in modes.items() if not k.startswith("direct")), modes
+    rm = out["rank_mode_rccl"]
+    assert "error" not in rm and rm["value"] > 0 and rm["rccl_ranks"] == gpus and rm["n_gpus"] == gpus and rm["rccl_calls_enqueued"] > 0, rm
+    assert rm["self_check"]["passed"] and rm["self_check"]["vs_one_gpu"] < 1e-9 and rm["exchange_us"] > 0
+    rm_modes = {k: v for k, v in rm["exchange_modes"].items() if k != "default"}
+    assert {"allgather_x2+allgather_p", "allgather_Ap", "direct_mailboxes", "direct_mailboxes, no split"} <= set(rm_modes), list(rm_modes)
+    assert all("error" not in m and m["value"] > 0 for m in rm_modes.values()), rm_modes
+    assert abs(rm["rel_residual_true"] / out["rel_residual_true"] - 1) < 1e-6       # both topologies solved the same system
+
+
+def _one_process_env(mock, gpus, **extra):
+    """`python bench.py --gpus N` on a one-GPU box: all shards of the one-process topology on GPU 0 (LAM_BENCH_DEVICE_IDS), one
+    hardware queue per stream; the rank-mode legs (N child processes) get the stream-ordered RCCL double through LD_PRELOAD."""
+    env = dict(os.environ, LAM_BENCH_DEVICE_IDS=",".join(["0"] * gpus), GPU_MAX_HW_QUEUES=str(2 * gpus + 4), LAM_HIP_DIRECT_SAME_DEVICE="1",
+               LD_PRELOAD=mock, MOCK_RCCL_TIMEOUT_MS="20000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("victim", ["one_direct", "rank_direct:init", "rank_mode:main"])
+def test_bench_headline_survives_a_dying_leg(mock_async, tmp_path, victim):
+    """The EXPERIMENTAL exchange (in-kernel flags over peer-mapped memory) has never run on separate GPUs; a memory fault on a peer
+    mapping would abort the process that runs it.  bench.py therefore runs it only in child processes of its own: here the test
+    hook makes every process of one leg kill itself with SIGKILL in the middle of its measurement (LAM_BENCH_KILL_LEG) -- the line
+    still comes out, with the headline and every other record intact and the dead leg as {"error": ...}.  The same for the
+    whole rank-mode leg."""
+    gpus = 2
+    env = _one_process_env(mock_async, gpus, LAM_BENCH_KILL_LEG=victim)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "3", "--order", "8192", "--leg-timeout", "90"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["self_check"]["passed"] and out["exchange_effective"] == 1
+    modes = {k: v for k, v in out["exchange_modes"].items() if k != "default"}
+    rm = out["rank_mode_rccl"]
+    if victim == "one_direct":
+        dead = modes["direct (experimental leg)"]
+        assert "signal 9" in dead["error"] and len([m for m in modes.values() if m.get("value", 0) > 0]) == 4, modes
+        assert rm["value"] > 0 and "direct_mailboxes" in rm["exchange_modes"]
+    elif victim.startswith("rank_direct"):
+        assert "signal 9" in rm["exchange_modes"]["direct (experimental leg)"]["error"], rm
+        assert rm["value"] > 0 and rm["rccl_ranks"] == gpus and len([m for m in modes.values() if m.get("value", 0) > 0]) == 6
+    else:
+        assert "error" in rm and "value" not in rm, rm
+        assert len([m for m in modes.values() if m.get("value", 0) > 0]) == 6
