@@ -36,6 +36,11 @@
 #include "../ConjugateGradient.hpp"
 #include "reference_system.hpp"
 
+// bytes one lam_hip_upload_rows call carries at most (tests/host_asan builds the loaders with a few KiB to walk the chunk loop)
+#ifndef LAM_LOADER_CHUNK_BYTES
+#define LAM_LOADER_CHUNK_BYTES (1ull << 30)
+#endif
+
 namespace LAM
 {
 
@@ -149,7 +154,7 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
         }
         (void)madvise(map, file_bytes, MADV_SEQUENTIAL);
         const FloatingType *data = reinterpret_cast<const FloatingType *>(static_cast<const char *>(map) + 16);
-        const uint64_t chunk_rows = std::max<uint64_t>(1, (1ull << 30) / (cols * sizeof(FloatingType)));
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (uint64_t)(LAM_LOADER_CHUNK_BYTES) / (cols * sizeof(FloatingType)));
         bool ok = true;
         for (int q = 0; q < total && ok; q++) {
             if (local != total && q != _rank) continue;
@@ -286,6 +291,7 @@ class ConjugateGradient_HIP_base : public ConjugateGradient<FloatingType>
     lam_hip_ctx *context() { return ensure_ctx() ? _ctx : nullptr; }
     void set_csv_output(bool on) { _print_csv = on; }
     void set_text_output(bool on) { _print_text = on; }
+    void set_comm_init_column(bool on) { _comm_init_column = on; }     // the NCCL variant's extra CSV column (0 without a communicator)
     // CSV: print t_gemv + t_exchange in the GEMV column (the reference's convention); also switched on by the environment
     // variable LAM_CSV_GEMV_PLUS_COMM=1 (for drivers compiled from the reference's own sources)
     void set_gemv_plus_comm(bool on) { _gemv_plus_comm = on; }

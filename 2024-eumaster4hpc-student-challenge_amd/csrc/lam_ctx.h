@@ -28,6 +28,9 @@ struct ShardBase {
     hipStream_t stream = nullptr;
     void *A = nullptr;           // nrows x n
     size_t A_capacity = 0;       // bytes behind A: the allocation is kept across lam_hip_set_problem calls (grow-only)
+    void *xfer_stage = nullptr;  // dense staging buffer of padded / bf16 row transfers (lam_hip_upload_rows / download_rows): kept
+    size_t xfer_stage_bytes = 0; // for the life of the context, grow-only -- a hipMalloc + hipFree of up to 1 GiB per chunk of a file
+                                 // load was a device-wide synchronisation each and left VRAM for the driver to wipe under the next kernels
     void *p = nullptr;           // n (replica)
     void *Ap = nullptr, *x = nullptr, *r = nullptr, *b = nullptr;  // nrows each
     void *tmp = nullptr;         // n: scratch vector (gemv op input / residual)
@@ -174,6 +177,7 @@ struct lam_hip_ctx {
                                        // library then verifies A = A^T itself where it can and says when the option is not effective
     uint64_t matrix_gen = 0, sym_checked_gen = ~0ull;   // the matrix contents changed / were last checked for symmetry
     bool sym_refused = false;      // the environment asked for the symmetric product and the matrix is not symmetric: general GEMV
+    bool told_sym_ineffective = false;
 
     // the symmetric product exists for every storage type and any n: one shard, or several row shards on the gather-Ap exchange
     // (inside CG only: every shard contributes a full-length vector per iteration, lam_exchange.h)
@@ -200,11 +204,7 @@ struct lam_hip_ctx {
     uint64_t ex1_stride_bytes() const { return (ex1_maxrows() * esz_v() + 7) / 8 * 8 + 8; }
 
     size_t esz_a() const { return dtype == LAM_HIP_F64 ? 8 : (dtype == LAM_HIP_F32 ? 4 : 2); }
-    static uint64_t pitch_for(uint64_t n, size_t ea)
-    {
-        const uint64_t align = n * ea >= 4096 ? 4096 / ea : 16 / ea;     // elements
-        return (n + align - 1) / align * align;
-    }
+    static uint64_t pitch_for(uint64_t n, size_t ea) { return lam::row_pitch(n, ea); }      // lam_host_plan.h
     // columns the 16-byte-vector kernels cover: n rounded up to a whole vector (the extra columns are zeros of the padding,
     // met by zeros behind the end of p)
     uint64_t ncols_vec() const { const uint64_t v = 16 / esz_a(); return (n + v - 1) / v * v; }
@@ -273,13 +273,8 @@ void matrix_changed(lam_hip_ctx *c)
     c->sym_refused = false;
 }
 
-void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows)
-{
-    // ConjugateGradient_CPU_MPI_OMP.hpp:176-184: n/P rows each, the remainder on the LAST rank
-    const uint64_t base = n / (uint64_t)P;
-    *row0 = base * (uint64_t)q;
-    *nrows = base + ((q == P - 1) ? n % (uint64_t)P : 0);
-}
+// ConjugateGradient_CPU_MPI_OMP.hpp:176-184: n/P rows each, the remainder on the LAST rank (lam_host_plan.h)
+void partition(uint64_t n, int P, int q, uint64_t *row0, uint64_t *nrows) { lam::partition_rows(n, P, q, row0, nrows); }
 
 // OPT-IN (environment LAM_HIP_QUIET_RCCL=1, set by this package's drivers, whose stdout is a one-line protocol): file
 // descriptor 1 points at stderr while at least one of these exists, i.e. for the duration of ncclCommInitRank, which

@@ -69,12 +69,12 @@ int measure_asymmetry(lam_hip_ctx *c, double *max_asym, double *max_abs)
 int env_symmetric_check(lam_hip_ctx *c)
 {
     if (!c->symmetric_from_env || c->opt_symmetric == 0) return 0;
-    static std::atomic<bool> told_ineffective{false};
     if (c->symv_wanted() && !c->symv_active() && !c->symv_multi_active()) {
-        if (!told_ineffective.exchange(true) && c->rank == 0)
+        if (!c->told_sym_ineffective && c->rank == 0)
             fprintf(stderr, "lam_hip: LAM_HIP_SYMMETRIC=%lld is not effective here: with several shards / ranks the symmetric product runs on "
                             "the gather-Ap exchange only (exchange is %lld; set LAM_HIP_EXCHANGE=1) -- using the general GEMV\n",
                     (long long)c->opt_symmetric, (long long)c->opt_exchange);
+        c->told_sym_ineffective = true;       // once per context
         return 0;
     }
     if (!c->symv_active() || c->sym_checked_gen == c->matrix_gen) return 0;
@@ -90,9 +90,7 @@ int env_symmetric_check(lam_hip_ctx *c)
     }
     fprintf(stderr, "lam_hip: LAM_HIP_SYMMETRIC refused: the matrix is not symmetric (max|A - A^T| = %.3e, max|A| = %.3e) -- using the "
                     "general GEMV\n", asym, amax);
-    c->sym_refused = true;
-    for (auto &s : c->sh)
-        s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
+    c->sym_refused = true;        // until the matrix changes; do_cg_init recomputes the partial counts right after this
     return 0;
 }
 

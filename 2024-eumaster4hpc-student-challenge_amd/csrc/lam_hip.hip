@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -320,8 +321,13 @@ static int rows_xfer(lam_hip_ctx *c, uint64_t row0, uint64_t nrows, void *host, 
             // whole rows go through a DENSE device staging buffer with ONE contiguous copy per chunk (the rate of the plain path:
             // the runtime pins the caller's pages), and a kernel moves them between the two layouts at HBM speed.
             const uint64_t chunk_rows = std::max<uint64_t>(1, ((upload ? 256ull : 1024ull) << 20) / (c->n * eh));   // D2H to pageable memory likes big pieces
-            DevBuf stage_buf;
-            HIPCHK(c, hipMalloc(&stage_buf.p, std::min<uint64_t>(chunk_rows, hi - lo) * c->n * eh));
+            const size_t need = std::min<uint64_t>(chunk_rows, hi - lo) * c->n * eh;
+            if (s.xfer_stage_bytes < need) {
+                if (s.xfer_stage) { (void)hipFree(s.xfer_stage); s.xfer_stage = nullptr; s.xfer_stage_bytes = 0; }
+                HIPCHK(c, hipMalloc(&s.xfer_stage, need));
+                s.xfer_stage_bytes = need;
+            }
+            struct { void *p; } stage_buf{s.xfer_stage};
             for (uint64_t r = lo; r < hi; r += chunk_rows) {
                 const uint64_t nr = std::min(chunk_rows, hi - r);
                 char *hp = (char *)host + (r - row0) * c->n * eh;
@@ -945,70 +951,14 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
 
 int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pairs, uint64_t *bad_interior, uint64_t *ntasks)
 {
-    if (n == 0 || shards < 1 || shards > kMaxShards || (uint64_t)shards > n || !bad_pairs || !bad_interior || !ntasks ||
-        (dtype != LAM_HIP_F64 && dtype != LAM_HIP_F32 && dtype != LAM_HIP_BF16))
-        return LAM_HIP_EINVAL;
-    const uint64_t vec = dtype == LAM_HIP_F64 ? 2 : (dtype == LAM_HIP_F32 ? 4 : 8), SS = (uint64_t)kBlock * vec, ncv = (n + vec - 1) / vec * vec;   // NV = 1, as launched
-    const bool cyc = shards > 1;
-    std::vector<uint8_t> count(n * n, 0);                 // count[i * n + j]: how often y_i += A_ij p_j is produced
-    auto bump = [&](uint64_t i, uint64_t j) { uint8_t &c = count[i * n + j]; if (c < 255) c++; };
-    *bad_interior = 0;
-    *ntasks = 0;
-    for (int q = 0; q < shards; q++) {
-        uint64_t R0 = 0, nloc = 0;
-        partition(n, shards, q, &R0, &nloc);
-        SymvPlan plan;
-        symv_plan(n, ncv, SS, R0, nloc, cyc, &plan);
-        const std::vector<SymvTask> &tasks = plan.tasks;
-        *ntasks += tasks.size();
-        // the index the second pass walks: every task is listed once for its strip, and its run holds it
-        {
-            const uint32_t *ix = plan.index.data();
-            const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
-            std::vector<uint8_t> seen(tasks.size(), 0);
-            for (uint32_t st = 0; st < nstrips; st++)
-                for (uint32_t k = ix[plan.ix.strip_base + st]; k < ix[plan.ix.strip_base + st + 1]; k++) {
-                    const uint32_t t = ix[plan.ix.strip_tasks + k];
-                    if (t >= tasks.size() || tasks[t].strip != st || seen[t]++) return LAM_HIP_EINVAL;
-                }
-            uint64_t rp_expect = 0;
-            for (size_t t = 0; t < tasks.size(); t++) {
-                const uint32_t j = ix[plan.ix.row8 + tasks[t].row0 / 8], h = tasks[t].nrows & ~kSymvFlags;
-                if (j >= plan.nruns) return LAM_HIP_EINVAL;
-                const uint32_t *run = ix + plan.ix.runs + 5 * j;
-                if (!seen[t] || t < run[0] || t >= run[0] + run[1] || tasks[t].row0 != run[2] || h != run[3] || h % 8 != 0 && tasks[t].row0 + h != nloc ||
-                    tasks[t].rp != rp_expect || tasks[t].rp != run[4] + (t - run[0]) * h)
-                    return LAM_HIP_EINVAL;
-                rp_expect += h;
-            }
-            if (rp_expect != plan.rowpart_elems) return LAM_HIP_EINVAL;
-        }
-        for (const SymvTask &t : tasks) {
-            const bool interior = (t.nrows & kSymvInterior) != 0, full = (t.nrows & kSymvFull) != 0;
-            const uint64_t h = t.nrows & ~kSymvFlags, c0 = (uint64_t)t.strip * SS;
-            if ((interior && !full) || (full && (c0 + SS > n || h % 8 != 0))) ++*bad_interior;   // "full": every load is made without a test
-            if (t.row0 + h > nloc) return LAM_HIP_EINVAL;
-            for (uint64_t r = 0; r < h; r++) {
-                const uint64_t grow = R0 + t.row0 + r;
-                for (uint64_t col = c0; col < c0 + SS; col++) {
-                    if (col >= ncv) { if (interior) ++*bad_interior; continue; }      // the kernel's `live` test (interior: no test)
-                    bool rs, cs;
-                    if (cyc) symv_use<true>(col, grow, n, &rs, &cs); else symv_use<false>(col, grow, n, &rs, &cs);
-                    if (interior) {                      // processed without any test: must be what the tests would have said
-                        if (!(rs && cs) || col >= n) ++*bad_interior;
-                        rs = cs = true;
-                    }
-                    if (col >= n) continue;              // padding column: the matrix holds zeros there, p likewise
-                    if (rs) bump(grow, col);             // y_grow += A[grow][col] p[col]
-                    if (cs) bump(col, grow);             // y_col  += A[grow][col] p[grow]  (A[col][grow] by symmetry)
-                }
-            }
-        }
+    if (dtype != LAM_HIP_F64 && dtype != LAM_HIP_F32 && dtype != LAM_HIP_BF16) return LAM_HIP_EINVAL;
+    // host-only arithmetic (lam_host_plan.h): the same code runs under AddressSanitizer in tests/host_asan
+    const uint64_t vec = dtype == LAM_HIP_F64 ? 2 : (dtype == LAM_HIP_F32 ? 4 : 8);
+    try {
+        return lam::symv_plan_check(n, shards, vec, kMaxShards, bad_pairs, bad_interior, ntasks) == 0 ? 0 : LAM_HIP_EINVAL;
+    } catch (const std::bad_alloc &) {
+        return LAM_HIP_ENOMEM;       // two bitmaps of n^2 / 8 bytes each
     }
-    uint64_t bad = 0;
-    for (uint8_t c : count) bad += c != 1;
-    *bad_pairs = bad;
-    return 0;
 }
 
 int lam_hip_dot(lam_hip_ctx *c, const void *x_host, const void *y_host, uint64_t n, double *result)

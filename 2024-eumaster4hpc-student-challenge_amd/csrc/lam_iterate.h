@@ -100,6 +100,10 @@ int do_cg_init(lam_hip_ctx *c)
     for (auto &sh_ : c->sh) sh_.waited_k = 0;
     if (c->direct_err) memset(c->direct_err, 0, 64);
     LAMCHK(env_symmetric_check(c));
+    // how many p.Ap partials the product step leaves (= what the consumer sums) depends on which product runs: settled here, at the
+    // one place where that is decided (options, a refused / re-admitted symmetric product)
+    for (auto &sh_ : c->sh)
+        sh_.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, sh_.nrows); });
     if (c->exchange2_wanted()) {
         // the state is initialised through RCCL (one-off); the iterations then run on the mailboxes
         LAMCHK(setup_direct(c));

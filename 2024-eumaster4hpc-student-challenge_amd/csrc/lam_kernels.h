@@ -35,6 +35,8 @@
 
 #include <type_traits>
 
+#include "lam_host_plan.h"
+
 namespace lam {
 
 constexpr int kBlock = 256;          // 4 waves of 64
@@ -1056,13 +1058,8 @@ constexpr int kSymvRowsLds = 256;      // row partials parked in LDS before they
 constexpr int kSymvRowsMax = 2048;     // rows of the tallest task
 constexpr int kSymvListChunk = 1024;   // entries of a strip's task list the second pass stages in LDS at a time
 constexpr int kSymvReduceRows = 32;    // rows per workgroup of the second pass = p.Ap partials per product: ceil(n / 32)
-struct SymvTask { uint32_t row0, nrows, strip, rp; };     // rp: where the task's row partials start in rowpart (elements)
-// What the second pass needs to find the partials, one uint32 array on the device (offsets in uint32 units):
-//   runs      5 words per row run: first task, number of tasks (the run's strips are consecutive tasks), first row, rows, and
-//             where the first task's row partials start in rowpart (the run's tasks follow at a pitch of `rows`)
-//   row8      for every 8 local rows the run they belong to (task heights are multiples of 8)
-//   strip_base / strip_tasks   per strip the list of the tasks that cover it, in task order
-struct SymvIndex { uint32_t runs, row8, strip_base, strip_tasks; };
+// SymvTask, SymvIndex, the task flags and the use rule symv_use<CYC> live in lam_host_plan.h: the host's planner and its exhaustive
+// check are built from the same definitions, also by plain g++ under AddressSanitizer (tests/host_asan).
 
 // lane exchanges of the transposed butterfly.  gfx950: v_permlane32_swap / v_permlane16_swap move both directions of a
 // halving step in one instruction (no select, no LDS crossbar); inside a 16-lane row DPP: rotation by 8 (= lane ^ 8),
@@ -1113,26 +1110,6 @@ __device__ __forceinline__ T wave_sum8(const T (&v)[8])
     t += dpp_t<0xb1>(t);                  // quad_perm [1,0,3,2]
     return t;
 }
-
-// Which elements a row uses.  One shard: the upper triangle (col >= row; the diagonal for the row side only).  Several row
-// shards (CYC): an upper-triangle split would leave the first shard with (2P-1)/P^2 of the work, so every row takes the CYCLIC
-// window of the (N-1)/2 columns behind its diagonal instead -- d = (col - row) mod N in [1, (N-1)/2], and for even N the antipode
-// d = N/2 for the rows of the upper half only: every pair {i, j} is covered once, every row does the same work, contiguous row
-// shards stay balanced.
-template <bool CYC>
-__host__ __device__ __forceinline__ void symv_use(uint64_t col, uint64_t grow, uint64_t n, bool *row_side, bool *col_side)
-{
-    if (!CYC) { *row_side = col >= grow; *col_side = col > grow; return; }
-    const uint64_t d = col >= grow ? col - grow : col + n - grow;
-    const bool in_window = (d >= 1 && d <= (n - 1) / 2) || ((n & 1) == 0 && d == n / 2 && grow < n / 2);
-    *row_side = d == 0 || in_window;
-    *col_side = in_window;
-}
-constexpr uint32_t kSymvFull = 0x40000000u;       // flag in SymvTask::nrows (host: the whole strip lies inside the matrix and the run is a
-                                                  // whole number of 8-row steps: no load needs a test, only the products may)
-constexpr uint32_t kSymvFlags = 0xc0000000u;
-constexpr uint32_t kSymvInterior = 0x80000000u;   // flag in SymvTask::nrows (host: every element of the task is used by both sides,
-                                                  // the whole strip lies inside the row, a whole number of 8-row steps)
 
 // Launched with kSymvLdsPerWorkgroup bytes of LDS in all (its row-partial buffer + idle dynamic LDS), i.e. THREE workgroups per
 // CU: the tasks' loads alone run at 7.22 TB/s with three workgroups per CU against 7.0 with the five its registers allow, the

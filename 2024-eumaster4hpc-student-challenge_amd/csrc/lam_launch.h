@@ -5,98 +5,7 @@
 namespace {
 
 // ---- typed implementation ----------------------------------------------------------------------
-// The symmetric product's plan for one shard (rows [R0, R0 + nloc) of an n x n matrix, strips of SS columns, ncv = columns a row
-// holds in whole vectors): pure host arithmetic, shared by the launcher below and by lam_hip_debug_symv_plan (a CPU test counts
-// that every directed pair (i <- j) is produced exactly once and that no task flagged interior has an unused element).
-// tasks: in dispatch order -- row run by row run, the strips of a run side by side --, which is also the order of the partials.
-struct SymvPlan {
-    std::vector<SymvTask> tasks;
-    std::vector<uint32_t> index;      // the device-side index (SymvIndex) ...
-    SymvIndex ix;                     // ... and where its parts start
-    uint32_t nruns = 0;
-    uint64_t rowpart_elems = 0;       // row partials of all tasks (one per row of every task)
-};
-void symv_plan(uint64_t n, uint64_t ncv, uint64_t SS, uint64_t R0, uint64_t nloc, bool cyc, SymvPlan *out)
-{
-    const uint32_t nstrips = (uint32_t)((ncv + SS - 1) / SS);
-    const uint64_t H = (n - 1) / 2;
-    // Task heights.  The partial stores are what separates the first pass from the rate of its loads alone (190 MB of them cost
-    // 4-10 % at N=65536, profiles/r04_symv2_probe.txt), and a task stores SS column partials whatever its height: tall tasks for
-    // the bulk, shorter ones only for what is dispatched last (the launch hands out tasks in list order and should end on short
-    // ones: the last ~8 % of the work).  One shard (the triangle: row r holds n - r elements): `tall` rows up to the row below
-    // which 60 % of the work lies, tall / 4 up to 92 %, at most 64 after; tall = the power of two that leaves ~1500 or more tall tasks, at most 2048 (fp64: 2048 from N = 65536 on,
-    // 512 at 32768); N < 16384:
-    // two classes, tall up to row 0.65 n and tall / 8 after (a
-    // launch wants some thousands of tasks).  Several shards (every row holds n / 2 elements): tall so that a shard has >= ~4000
-    // tasks, tall / 4 for its last 8 % of rows.
-    uint64_t tall = 32, mid_from, small_from;
-    bool two_classes = cyc;
-    if (!cyc) {
-        while (tall < 2048 && 2 * tall * 3000 <= n * nstrips) tall *= 2;     // ~1500 or more tall tasks: n / tall runs x nstrips / 2 strips
-        mid_from = (uint64_t)((1.0 - std::sqrt(0.40)) * (double)n);
-        small_from = (uint64_t)((1.0 - std::sqrt(0.08)) * (double)n);
-        if (n < 16384) {                                           // small systems: the second pass's fixed cost counts, fewer tasks win
-            two_classes = true;
-            mid_from = small_from = (uint64_t)(0.65 * (double)n);
-        }
-    } else {
-        tall = 8;
-        const uint64_t strips_per_run = n / 2 / SS + 2;
-        while (tall < 1024 && nloc * strips_per_run / (2 * tall) >= 4000) tall *= 2;
-        mid_from = small_from = (uint64_t)(0.92 * (double)nloc);
-    }
-    const uint64_t mid = std::max<uint64_t>(8, cyc ? tall / 4 : (two_classes ? tall / 8 : tall / 4));
-    const uint64_t small = two_classes ? mid : std::min<uint64_t>(64, std::max<uint64_t>(8, tall / 16));
-    mid_from = mid_from / tall * tall;                            // classes start on multiples of the height before them
-    small_from = std::max(mid_from, small_from / mid * mid);
-    auto meets = [](uint64_t a0, uint64_t a1, uint64_t b0, uint64_t b1) { return a0 <= b1 && b0 <= a1; };   // closed intervals
-    std::vector<SymvTask> &tasks = out->tasks;
-    std::vector<uint32_t> runs, row8((nloc + 7) / 8, 0);
-    std::vector<std::vector<uint32_t>> per_strip(nstrips);
-    for (uint64_t r = 0; r < nloc;) {
-        const uint64_t h = std::min<uint64_t>(nloc - r, r < mid_from ? tall : (r < small_from ? mid : small));
-        const uint64_t ga = R0 + r, gb = ga + h;                   // global rows [ga, gb)
-        const uint32_t run = (uint32_t)(runs.size() / 5), first = (uint32_t)tasks.size();
-        for (uint32_t st = 0; st < nstrips; st++) {
-            const uint64_t c0 = (uint64_t)st * SS, c1 = std::min<uint64_t>(c0 + SS, n) - 1;     // real columns [c0, c1]
-            const bool full = c0 + SS <= n && h % 8 == 0;             // the whole strip inside the matrix (no padding column), whole 8-row steps
-            bool needed, interior = full;
-            if (!cyc) {
-                needed = c1 >= ga;                                 // some column at or right of the first row's diagonal
-                interior = interior && c0 >= gb;                   // every column right of every row
-            } else {
-                // the union of the rows' windows (diagonal and antipode included) is the cyclic interval [ga, gb - 1 + n / 2]
-                needed = meets(c0, c1, ga, gb - 1 + n / 2) || meets(c0 + n, c1 + n, ga, gb - 1 + n / 2);
-                bool in = false;
-                for (uint64_t k = 0; k < 2; k++) {                 // the strip as it lies behind the rows, unwrapped
-                    const uint64_t u0 = c0 + k * n, u1 = c0 + SS - 1 + k * n;
-                    in = in || (u0 >= gb && u1 - ga <= H);         // 1 <= d <= (n - 1) / 2 for every row and column
-                }
-                interior = interior && in;
-            }
-            if (!needed) continue;
-            per_strip[st].push_back((uint32_t)tasks.size());
-            tasks.push_back({(uint32_t)r, (uint32_t)h | (interior ? kSymvInterior : 0u) | (full ? kSymvFull : 0u), st, (uint32_t)out->rowpart_elems});
-            out->rowpart_elems += h;
-        }
-        runs.insert(runs.end(), {first, (uint32_t)tasks.size() - first, (uint32_t)r, (uint32_t)h, tasks.size() > first ? tasks[first].rp : 0u});
-        for (uint64_t q = r / 8; q < (r + h + 7) / 8; q++) row8[q] = run;
-        r += h;
-    }
-    out->nruns = (uint32_t)(runs.size() / 5);
-    std::vector<uint32_t> &index = out->index;
-    out->ix.runs = 0;
-    index = runs;
-    out->ix.row8 = (uint32_t)index.size();
-    index.insert(index.end(), row8.begin(), row8.end());
-    out->ix.strip_base = (uint32_t)index.size();
-    uint32_t acc = 0;
-    for (uint32_t st = 0; st < nstrips; st++) { index.push_back(acc); acc += (uint32_t)per_strip[st].size(); }
-    index.push_back(acc);
-    out->ix.strip_tasks = (uint32_t)index.size();
-    for (uint32_t st = 0; st < nstrips; st++) index.insert(index.end(), per_strip[st].begin(), per_strip[st].end());
-}
-
+// (the symmetric product's plan -- SymvPlan, symv_plan -- is host-only arithmetic: lam_host_plan.h)
 template <typename TA, typename TV>
 struct Impl {
     static constexpr int VEC = MatVec<TA>::N;
@@ -422,6 +331,8 @@ void free_shard(ShardBase &s, bool keep_matrix = false)
     void *const keepA = keep_matrix ? s.A : nullptr;
     const size_t keepCap = keep_matrix ? s.A_capacity : 0;
     if (keep_matrix) s.A = nullptr;
+    // the row-transfer staging buffer belongs to the context, not to a problem: released only with the matrix
+    if (!keep_matrix && s.xfer_stage) { (void)hipFree(s.xfer_stage); s.xfer_stage = nullptr; s.xfer_stage_bytes = 0; }
     void *ptrs[] = {s.A, s.p, s.Ap, s.x, s.r, s.b, s.tmp, s.part_gemv, s.part_vec, s.gather_a, s.gather_b, s.sc,
                     s.r_full, s.ap_gather, s.symv_rowpart, s.symv_colpart, s.symv_tasks, s.symv_index, s.symv_gather, s.part_aux};
     for (void *q : ptrs) if (q) (void)hipFree(q);

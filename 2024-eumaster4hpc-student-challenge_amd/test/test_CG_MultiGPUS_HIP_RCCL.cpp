@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <vector>
 
 #include <unistd.h>
 
@@ -42,6 +43,8 @@ void usage(const char *exe)
     printf("                  exp(3.5 U[-1,1]), rhs U[-1,1], its srand/rand streams), built on the device without the files\n");
     printf("  -t <type>       f64 (default, what the reference drivers hard-code), f32, or bf16 (bf16 matrix\n");
     printf("                  storage, fp32 vectors); files hold doubles for f64 and floats otherwise\n");
+    printf("  -P <shards>     ONE process drives <shards> row shards, dealt round-robin over the visible GPUs (the reference's\n");
+    printf("                  test_CG_MultiGPUS_CUDA topology with this driver's flags and CSV; not under a multi-rank launcher)\n");
     printf("  -g              CSV: the GEMV column is GEMV + exchange (collectives / joins), the reference's convention\n");
     printf("  -v              Verbose mode\n");
     printf("  -h              Show this help message\n");
@@ -54,7 +57,7 @@ struct Options {
     double rel_error = 1e-9, cond = 1e4;
     size_t rows = 0;
     long seed = -1;
-    int ref_seed = 0;
+    int ref_seed = 0, shards = 0;
     bool have_ref_seed = false;
     bool verbose = false, mode_generate = false, mode_load = false, bf16_storage = false, gemv_plus_comm = false;
 };
@@ -93,7 +96,7 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
     const char *precision = "f64";
 
     int opt;
-    while ((opt = getopt(argc, argv, "hvgA:b:o:i:e:s:r:R:c:t:")) != -1) {
+    while ((opt = getopt(argc, argv, "hvgA:b:o:i:e:s:r:R:c:t:P:")) != -1) {
         switch (opt) {
         case 'A':
         case 'b':
@@ -120,6 +123,7 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
         case 'c': cond = atof(optarg); break;
         case 't': precision = optarg; break;
         case 'g': o.gemv_plus_comm = true; break;
+        case 'P': o.shards = atoi(optarg); break;
         case 'v': verbose = true; break;
         case 'h':
             if (root) usage(argv[0]);
@@ -139,6 +143,10 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
         fprintf(stderr, "No GPU: %s\n", lam_hip_last_error(nullptr));
         return 1;
     }
+    if (o.shards != 0 && (o.shards < 1 || o.shards > 16 || L.size > 1 || !strcmp(precision, "bf16"))) {
+        if (root) fprintf(stderr, "Option -P takes 1 ... 16 shards, runs as ONE process (no multi-rank launcher) and in f64 / f32\n");
+        return 1;
+    }
     int rc;
     if (!strcmp(precision, "f64")) rc = run<double>(L, o, ndev);
     else if (!strcmp(precision, "f32")) rc = run<float>(L, o, ndev);
@@ -152,8 +160,27 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
 
 // the reference drivers hard-code <double> (test_CG_CPU_MPI_OMP.cpp:46,132); the class template is
 // instantiated for float too, so the precision is a run-time choice here
+template <typename Solver>
+int run_solver(Solver &cg, const lam_bootstrap::Launch &L, const Options &o, int procs);
+
 template <typename T>
 int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
+{
+    if (o.shards > 0) {
+        // one process, o.shards row shards dealt round-robin over the devices (several per GPU when there are fewer GPUs)
+        std::vector<int> devs;
+        for (int q = 0; q < o.shards; q++) devs.push_back(q % ndev);
+        LAM::ConjugateGradient_MultiGPUS_HIP<T> cg(devs);
+        cg.set_text_output(false);
+        cg.set_comm_init_column(true);       // same ten CSV columns as the rank mode (the column is 0: no communicator)
+        return run_solver(cg, L, o, o.shards);
+    }
+    LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<T> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id, o.bf16_storage);
+    return run_solver(cg, L, o, L.size);
+}
+
+template <typename Solver>
+int run_solver(Solver &cg, const lam_bootstrap::Launch &L, const Options &o, int procs)
 {
     const char *matrix_file = o.matrix_file, *rhs_file = o.rhs_file, *sol_file = o.sol_file;
     const int max_iters = o.max_iters;
@@ -163,7 +190,6 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
     const int ref_seed = o.ref_seed;
     const bool have_ref_seed = o.have_ref_seed;
     const bool verbose = o.verbose, mode_generate = o.mode_generate, root = L.rank == 0;
-    LAM::ConjugateGradient_MultiGPUS_HIP_RCCL<T> cg(L.rank, L.size, L.local_rank % ndev, L.unique_id, o.bf16_storage);
     cg.set_csv_output(!verbose);
     if (o.gemv_plus_comm) cg.set_gemv_plus_comm(true);
     if (cg.context() == nullptr) return 1;      // creates the RCCL communicator (collective)
@@ -175,7 +201,8 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
         if (mode_generate) printf("  rows: %zu  (%.3f GB)\n", rows, rows * (double)rows * 8 / 1024.0 / 1024.0 / 1024.0);
         else printf("  input_file_matrix: %s\n  input_file_rhs:    %s\n", matrix_file, rhs_file);
         printf("  output_file_sol:   %s\n  max_iters:         %d\n  rel_error:         %e\n", sol_file, max_iters, rel_error);
-        printf("  Number of processes: %d (1 GPU each)\n\n", L.size);
+        if (o.shards > 0) printf("  One process, %d row shards\n\n", o.shards);
+        else printf("  Number of processes: %d (1 GPU each)\n\n", L.size);
     }
     const auto t0 = clk::now();
     bool ok;
@@ -188,7 +215,7 @@ int run(const lam_bootstrap::Launch &L, const Options &o, int ndev)
         if (root) fprintf(stderr, "Failed to read matrix\n");
         return 1;
     }
-    if (root && !verbose) std::cout << L.size << "," << 1 << "," << t_load << ",";
+    if (root && !verbose) std::cout << procs << "," << 1 << "," << t_load << ",";
     if (verbose && root) printf("Matrix ready in %f s\n", t_load);
     if (mode_generate) ok = (seed >= 0 || have_ref_seed) ? true : cg.generate_rhs();
     else ok = cg.load_rhs_from_file(rhs_file);

@@ -220,7 +220,9 @@ int lam_hip_check_symmetry(lam_hip_ctx *ctx, double *max_abs_asymmetry);
  * and reports how many directed products (y_i += A_ij p_j, i and j in [0, n)) are produced not exactly once (*bad_pairs, must be
  * 0) and how many elements of tasks flagged "interior" -- which the kernel processes without any test -- are not used by both
  * sides or lie outside the matrix (*bad_interior, must be 0); *tasks = number of tasks.  shards == 1: the upper triangle; more:
- * cyclic half windows.  O(n^2) time, n^2 bytes of memory: for tests (n <= ~8192).  No reference counterpart. */
+ * cyclic half windows.  O(n^2) time, n^2 / 4 bytes of memory (two bitmaps: 1 GiB at n = 65536, 4 GiB at n = 131072).  The
+ * arithmetic is csrc/lam_host_plan.h, which tests/host_asan also builds with g++ -fsanitize=address,undefined.  No reference
+ * counterpart. */
 int lam_hip_debug_symv_plan(uint64_t n, int shards, int dtype, uint64_t *bad_pairs, uint64_t *bad_interior, uint64_t *tasks);
 
 /* Agreement across ranks (collective in rank mode, identity otherwise): *global_ok = 1 iff every rank passed
@@ -238,114 +240,48 @@ int lam_hip_rccl_version(int *version);
 int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
 
 /* ---- options --------------------------------------------------------------------------------- */
-/* name/value pairs; unknown names -> LAM_HIP_EINVAL.
- *   "exchange"      RANK MODE (lam_hip_create_rank).  0 (default): per iteration an 8-byte-per-rank ncclAllGather for p.Ap and for
- *                   r.r (summed in rank order by the consumer kernel: deterministic, identical on every rank) and
- *                   ncclAllGather(p slices) -- sliced x, r, Ap, replicated p.  1: ONE ncclAllGather of
- *                   [Ap slice | p.Ap partial] per iteration, r and p kept full-length on every rank and
- *                   updated redundantly (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505); needs
- *                   N % ranks == 0, otherwise 0 is used ("exchange_effective" tells).  2: DIRECT exchange
- *                   (EXPERIMENTAL: pinned on one GPU with ranks as threads and as processes, never yet run on
- *                   separate GPUs; lam_hip_solve therefore checks the recomputed residual against the recursive
- *                   one afterwards and solves again on exchange 0 if they disagree -- options "verify_direct",
- *                   "direct_fallbacks"), no
- *                   collective call inside the iteration: every rank maps the other ranks' p replicas and
- *                   mailboxes (HIP IPC; set up once per problem through the communicator) and the kernels store
- *                   their partial dot products and p slices straight into them over xGMI, tagged with the
- *                   iteration; consumers poll the tags (bounded).  Results are bit-identical to exchange 0.
- *                   Falls back to 0 when a mapping cannot be made (all ranks agree).  Re-run cg_init/solve
- *                   after changing it.  Environment LAM_HIP_EXCHANGE sets the default of new contexts (the value 2 only
- *                   together with LAM_HIP_EXPERIMENTAL_DIRECT=1: lam_hip_cg_init + lam_hip_cg_iterate do not check
- *                   themselves the way lam_hip_solve does, so the environment alone cannot make the experimental exchange
- *                   anybody's default; cross-GPU parity of exchange 2 is UNPINNED until it has run on separate devices).
- *                   ONE PROCESS WITH SEVERAL SHARDS (lam_hip_create): 1 (DEFAULT) = gather-Ap: every shard's GEMV stores its Ap
- *                   slice and its p.Ap partial straight into every shard's gather buffer (peer stores over xGMI), ONE event
- *                   join per iteration, r and p full-length on every shard and updated redundantly -- the layout of the
- *                   reference CPU path (CPU_MPI_OMP.hpp:476,505) and the gather of the single-process CUDA class
- *                   (GPU/local/ConjugateGradient_MultiGPUS_CUDA.cu:362-376); bit-identical to the rank mode's exchange 1.
- *                   Needs N % shards == 0, otherwise 0 is used.  0 = sliced vectors and three event joins per iteration
- *                   (p.Ap partials, r.r partials, p slices).  Both are ordered by HIP events only (system-scope release /
- *                   acquire at the event): host time to enqueue one iteration at 8 shards 0.15 ms (1) against 0.59 ms (0),
- *                   profiles/r04_host_enqueue_cost.txt.  2 (EXPERIMENTAL) uses the in-kernel flag exchange between the local
- *                   shards -- no event, no stream wait, 2 launches per shard with "overlap" 0: 0.05 ms, same bits as 0.
- *                   Needs every shard on a device of its own (kernels of one shard wait for kernels of the others); shards
- *                   sharing a device get it only with LAM_HIP_DIRECT_SAME_DEVICE=1 and one hardware queue per stream
- *                   (tests), else 0 is used.
- *   "exchange_join" one process, exchange 1: 1 (default with more than two shards) = the iteration's join goes through shard
- *                   0's stream: it waits for the other shards' posts and records ONE join event they wait for -- 2(P-1)+1
- *                   runtime calls, two event hops on the device; 0 = every stream waits for every other one -- P(P-1) calls,
- *                   one hop.  Same bits.
- *   "symmetric"     every storage type, any N: the matrix-vector product reads every pair {A[i][j], A[j][i]} ONCE (A must equal
- *                   its transpose, which CG requires anyway; lam_hip_check_symmetry verifies it) -- half the HBM traffic per
- *                   iteration, 1.7-1.8x the iteration rate at N >= 20000 on one GPU.  One shard: the upper triangle.  Several row
- *                   shards (either multi-GPU topology, on exchange 1, inside CG): every row takes the cyclic window of (N-1)/2
- *                   columns behind its diagonal, so contiguous row shards stay balanced, and each shard contributes a full-length
- *                   vector to the iteration's exchange.  1 = where it pays (from 192 MiB of matrix on: fp64 N >= 5017, fp32 7095,
- *                   bf16 10033; below, the fixed cost of its two passes outweighs the halved stream), 2 = at every size, 0
- *                   (default) = the reference's general row-partitioned
- *                   GEMV.  Same results to rounding (another summation order).  "symmetric_effective" tells whether the current
- *                   context uses it.  Environment LAM_HIP_SYMMETRIC = 1 | 2 sets it for new contexts (drivers).
- *   "finalize"      several shards: 1 (default) = the last workgroup of the GEMV / update kernel reduces the
- *                   shard's partial dot product inside the launch (3 launches per iteration for any shard
- *                   count); 0 = separate 1-workgroup reduction launches (5 per iteration; the round-1 chain, kept for A/B
- *                   measurements: TUNING BUILD ONLY, the product library refuses it).
- *   "fuse_update"   one shard, exchange 1 and exchange 2: 1 (default) = the x, r and p updates of an iteration are ONE launch
- *                   (the r.r total is handed over inside the launch): an iteration is two launches per shard -- GEMV + vector
- *                   step; with exchange 2 and overlap 0 that launch also waits for the peers' p slices.  0 = two kernels.
- *                   Same bits either way.
- *                   The fused launch's workgroups wait for each other, so it is used only when cg_init finds that
- *                   the whole grid can be resident at once (occupancy x CU count; "fuse_effective" tells,
- *                   "assume_cus" overrides the CU count for tests); otherwise the two-kernel form runs.
- *   The options marked TUNING BUILD ONLY are experiments that were built, tested, measured and did not win.  They exist in
- *   liblam_hip_tuning.so (`make tuning`, same ABI; tools and tests load it through the environment variable LAM_HIP_LIB);
- *   the product library refuses to switch them on (LAM_HIP_EINVAL) and accepts switching them off.
- *   "persistent"    TUNING BUILD ONLY.  one shard, fp64/fp32, even N a multiple of the 16-byte vector width: 1 = EXPERIMENT, whole CG
- *                   iterations inside one launch ("persist_chunk", default 32, iterations per launch): resident GEMV
- *                   workers + one reducer workgroup, two in-launch hand-overs per iteration, same bits as the
- *                   two-launch chain; measured 0.7-2 % SLOWER (profiles/r03_persistent_vs_two_launch.txt), so 0 is the
- *                   default.  "persistent_effective" / "persistent_workers" tell what cg_init decided (the grid must
- *                   be resident at once: occupancy x CU count).
- *   "gemv_timing"   T (default 8): a HIP-event pair brackets the GEMV of every T-th iteration (lam_hip_stats.t_gemv is
- *                   their average); 1 = every iteration (costs ~8 us per iteration: each record is a marker packet
- *                   between the kernels), 0 = never (t_gemv = 0).  The host follows the iteration through a progress
- *                   word in pinned memory, not through events.
- *   "host_threads"  TUNING BUILD ONLY.  one process, several shards, exchange 0: 1 = every shard is enqueued by a host thread of its own (the
- *                   reference's OpenMP-thread-per-device shape); 0 (default) = one thread enqueues all shards.
- *   "exchange_hub"  TUNING BUILD ONLY.  one process, more than two shards, exchange 0: 1 = the shards' streams meet at one join event per exchange
- *                   (2P+1 runtime calls) instead of every stream waiting for every other one (P(P-1)); 0 (default).
- *                   Measured host cost of both: profiles/r03_host_enqueue_cost.txt.  Same bits in every combination.
- *   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "host_enqueue_ns" (get only): runtime calls issued and host
- *                   time spent by the iteration loop so far (diagnostics, tools/host_enqueue_cost.py).
- *   "row_pitch"     (get only) elements between the starts of two consecutive matrix rows on the device: N rounded up to whole
- *                   4-KiB pages (to 16 bytes for rows shorter than a page); the padding is zero.
- *   "host_cpu_ns"   (get only) CPU time (CLOCK_THREAD_CPUTIME_ID) the calling thread has spent inside lam_hip_cg_iterate:
- *                   the host SLEEPS between its polls of the iteration's progress word (a quarter of the observed iteration
- *                   time, 20 us .. 1 ms; it runs 4 iterations ahead of the one it awaits, so the queue never drains), it
- *                   does not spin a core per solve.
- *   "reuse_matrix"  1 (default) = lam_hip_set_problem keeps the matrix allocation when it is large enough for the new
- *                   problem (grow-only: a context never hands tens of GB back between problems); 0 = free + allocate.
- *   "upload_staging" lam_hip_upload_rows: 1 = copy through two pinned staging buffers (host memcpy overlapped
- *                   with the DMA); 0 (default) = hand the caller's pages to the runtime directly.
- *   "collectives_enqueued" (get only) RCCL calls this context has enqueued so far -- equal on all ranks.
- *   "overlap"       rank mode, exchange 0: 1 (default) puts the all-gather of p on a second stream under the
- *                   GEMV panel of the rank's own columns; 0 keeps everything on one stream.  Exchange 2: 1 runs
- *                   that own-columns panel in front of the wait for the peers' p slices; 0 waits first and
- *                   launches the GEMV once.
- *   "gemv_variant"  -1 (default) = production GEMV shape for the dtype: 13 for fp64 (cooperative rows, 2 rows per 8-wave
- *                   workgroup), 10 for fp32 (the same with 4 waves), 0 for bf16 (4 rows per wave).  17 (4 rows per 8-wave
- *                   workgroup) is an alternative in the product library: 0.5-0.8 % faster than 13 for matrices of exactly 16
- *                   column tiles (N = 65536 and its row shards), slower nearly everywhere else
- *                   (profiles/r04_variant_vs_size.txt) -- never selected by size.  Every other shape
- *                   is TUNING BUILD ONLY ("tuning_variants" tells which build this is) and refused with LAM_HIP_EINVAL by the
- *                   product library: 1-9, 11, 12, 14-16, 18, 23, 24 tile / cooperative-row shapes (tools/gemv_probe.py), 19-22 the MFMA-fed
- *                   bf16 GEMV (20: p rounded to bf16, 21: p exact as three bf16 terms; LAM_HIP_BF16 only) -- BASELINE
- *                   configs[3]'s comparison, measured slower than the VALU kernel (bench.py measures it in a child process
- *                   on the tuning build).
- *   "nt_loads"      1 (default) = non-temporal loads for the matrix stream.
- *   "force_generic" 1 = use the any-alignment scalar-peel GEMV (tests and comparisons; since the rows are padded on the device
- *                   the vector kernels serve every N and this kernel is never chosen by itself).
- *   "probe_rows"    lam_hip_gemv_only: use only the first ROWS rows of a shard (a P-way split's shape).
- *   "panel_lo/hi"   testing: split the CG GEMV into the column panel [lo,hi) + the rest (accumulated). */
+/* name/value pairs; unknown names -> LAM_HIP_EINVAL.  Options that change which kernels an iteration uses need a new
+ * lam_hip_cg_init.  Everything here is the PRODUCT; the experiments that were built, measured and lost (persistent launch,
+ * enqueue threads, hub join, separate reduction launches, MFMA-fed GEMV, 19 GEMV tuning shapes) exist only in
+ * liblam_hip_tuning.so and are described in include/lam_hip_tuning.md -- this library refuses to switch them on.
+ *
+ *   "exchange"      how row shards exchange per iteration.  Default 1 for lam_hip_create with several shards, 0 for
+ *                   lam_hip_create_rank; environment LAM_HIP_EXCHANGE sets the default of new contexts.
+ *                     1  gather-Ap: ONE exchange of [Ap slice | p.Ap part] per iteration (one ncclAllGather / one event
+ *                        join), r and p full-length on every shard (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505).
+ *                        Any N >= shards: records hold the longest slice of the reference's uneven partition (:176-196).
+ *                     0  sliced vectors: 8-byte-per-rank all-gathers for p.Ap and r.r (summed in rank order by the consumer)
+ *                        + all-gather of the p slices / three event joins.
+ *                     2  DIRECT, EXPERIMENTAL (never yet run on separate GPUs; cross-GPU parity unpinned): peer-mapped
+ *                        mailboxes and p replicas, tagged in-kernel hand-overs, no collective and no event in the iteration;
+ *                        bit-identical to 0.  lam_hip_solve verifies itself on it ("verify_direct", "direct_fallbacks") and
+ *                        falls back to 0; from the environment only together with LAM_HIP_EXPERIMENTAL_DIRECT=1; shards
+ *                        sharing a device get it only with LAM_HIP_DIRECT_SAME_DEVICE=1 (tests).
+ *                   "exchange_effective" (get) tells what the current CG state runs on.
+ *   "exchange_join" one process, exchange 1: 1 (default for > 2 shards) = the join goes through shard 0's stream
+ *                   (2(P-1)+1 runtime calls), 0 = every stream waits for every other one (P(P-1)).  Same bits.
+ *   "overlap"       rank mode, exchange 0: 1 (default) = all-gather of p on a second stream under the own-slice GEMV panel.
+ *                   Exchange 2: 1 = own-slice panel in front of the wait for the peers' slices, 0 = wait first.
+ *   "symmetric"     the product reads every pair {A[i][j], A[j][i]} ONCE (A must equal its transpose): half the HBM traffic.
+ *                   One shard: the upper triangle; several (exchange 1): cyclic half windows per row, each shard contributes
+ *                   a full-length vector to the exchange.  1 = where it pays (from 192 MiB of matrix on), 2 = always, 0
+ *                   (default) = the reference's general GEMV.  Same results to rounding.  "symmetric_effective" (get).
+ *                   Environment LAM_HIP_SYMMETRIC = 1 | 2 (drivers): the library then checks A = A^T itself once per matrix on
+ *                   one shard (warns at rounding level, refuses beyond), selects exchange 1 in rank mode unless
+ *                   LAM_HIP_EXCHANGE is set, and says on stderr when the option is not effective.
+ *   "fuse_update"   1 (default) = the x, r, p updates of an iteration are ONE launch (r.r handed over inside the launch):
+ *                   2 launches per shard and iteration.  Used only when the whole grid of all shards / ranks on the device
+ *                   is resident ("fuse_effective" tells; "assume_cus" overrides the CU count for tests).  Same bits.
+ *   "gemv_timing"   T (default 8): HIP-event pairs bracket the GEMV -- and the exchange step(s) -- of every T-th iteration
+ *                   (lam_hip_stats.t_gemv / t_exchange); 0 = never.
+ *   "gemv_variant"  -1 (default) = production shape of the dtype (13 fp64, 10 fp32, 0 bf16); 17 = 4 rows per 8-wave
+ *                   workgroup (faster at exactly 16 column tiles only).  Others: tuning build.
+ *   "nt_loads" 1, "force_generic" 0, "probe_rows", "panel_lo"/"panel_hi"   kernel-level switches for tests and probes.
+ *   "reuse_matrix"  1 (default) = lam_hip_set_problem keeps the matrix allocation when it is large enough (grow-only).
+ *   "upload_staging" 1 = lam_hip_upload_rows copies through two pinned staging buffers (default 0: measured slower).
+ *   get only: "row_pitch" (elements between rows on the device), "collectives_enqueued", "rccl_ranks" (ncclCommCount of
+ *                   the context's communicator, 0 without one), "ranks_on_device", "host_cpu_ns", "host_enqueue_ns",
+ *                   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "tuning_variants" (1 in the tuning build). */
 int lam_hip_set_option(lam_hip_ctx *ctx, const char *name, int64_t value);
 int lam_hip_get_option(const lam_hip_ctx *ctx, const char *name, int64_t *value);
 

@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU; skipped unless LAM_RUN_SLOW=1 (its output is committed under profiles/)")
 
 
 @pytest.fixture(scope="session")

@@ -80,5 +80,35 @@ def file_grid():
     print(f"{len(out['entries'])} file-mode sizes -> {path}: " + ", ".join(f"{e['n']}: {e['iters_min']}-{e['iters_max']}" for e in out["entries"]))
 
 
+def scaling_tables():
+    """The reference's published GPU scaling series (TESTS/results/STRONG_SCALABILITY_GPU_MPI.txt:15-43: N = 20000 / 40000 / 50000 at
+    1 ... 16 GPUs, file mode on its generator's matrices; WEAK_SCALABILITY_GPU_MPI.txt:15-20) as data: every CSV line with the line
+    number it came from, plus the speed-up of the whole CG (column 9, and of the iteration, column 6) over the series' own P = 1 line.
+    tools/sweep.py --grid strong | weak prints this package's numbers next to them."""
+    pat = re.compile(r"(\d+),(\d+),(\d+),([\d.e+-]+),([\d.e+-]+),([\d.e+-]+),(\d+),([\d.e+na-]+),([\d.e+-]+)")
+    out = {"what": "GPU runs of the reference (test_CG_MultiGPUS_CUDA_MPI.out, A100 40 GB, 4 GPUs per node, MeluXina), file mode on its generator's "
+                   "matrices, tol 1e-9: CSV columns N,procs,threads,t_load,t_gemv(incl. bcast+gather),t_iter,iters,err,t_cg",
+           "grid_script": "TESTS/GPU_SCRIPTS/GPU_2_NODE.sh:17-40", "strong": [], "weak": []}
+    for key, path in (("strong", "/root/reference/TESTS/results/STRONG_SCALABILITY_GPU_MPI.txt"), ("weak", "/root/reference/TESTS/results/WEAK_SCALABILITY_GPU_MPI.txt")):
+        for ln, line in enumerate(open(path), 1):
+            m = pat.match(line.strip())
+            if not m:
+                continue
+            n, p_, _, t_load, t_gemv, t_iter, iters, err, t_cg = m.groups()
+            out[key].append({"n": int(n), "procs": int(p_), "t_gemv": float(t_gemv), "t_iter": float(t_iter), "iters": int(iters), "err": err,
+                             "t_cg": float(t_cg), "converged": int(iters) < 10001, "source": f"TESTS/results/{os.path.basename(path)}:{ln}"})
+    for n in sorted({e["n"] for e in out["strong"]}):
+        series = [e for e in out["strong"] if e["n"] == n]
+        base = next((e for e in series if e["procs"] == 1), None)
+        for e in series:
+            # the N = 50000 series has no converged P = 1 run (it printed -nan): its per-iteration time is still a valid base
+            e["speedup_iter_vs_p1"] = round(base["t_iter"] / e["t_iter"], 3) if base else None
+            e["speedup_cg_vs_p1"] = round(base["t_cg"] / e["t_cg"], 3) if base and base["converged"] and e["converged"] else None
+    path = os.path.join(os.path.dirname(OUT), "reference_scaling.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(f"{len(out['strong'])} strong + {len(out['weak'])} weak scaling lines -> {path}")
+
+
 if __name__ == "__main__":
     main()
+    scaling_tables()

@@ -44,7 +44,8 @@ def test_build_id_covers_every_source_of_the_translation_unit(lam):
     headers = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, pkg, "csrc", "*.h")))
     assert files[1:-1] == headers and {"lam_kernels.h", "lam_ctx.h", "lam_launch.h", "lam_exchange.h", "lam_iterate.h"} <= {os.path.basename(h) for h in headers}
     # every header is really included by the translation unit, and the Makefile hashes the same list
-    tu = open(os.path.join(ROOT, pkg, "csrc", "lam_hip.hip")).read()
+    # (directly, or -- lam_host_plan.h, the host-only arithmetic that tests/host_asan also builds -- through lam_kernels.h)
+    tu = open(os.path.join(ROOT, pkg, "csrc", "lam_hip.hip")).read() + open(os.path.join(ROOT, pkg, "csrc", "lam_kernels.h")).read()
     assert all(f'#include "{os.path.basename(h)}"' in tu for h in headers)
     mk = open(os.path.join(ROOT, pkg, "Makefile")).read()
     assert "$(sort $(wildcard $(HERE)csrc/*.h))" in mk and "$(STAMP)" in mk
@@ -165,3 +166,28 @@ def test_symmetric_product_plan_covers_every_pair_once(lam, dtype):
     # a larger one with many interior tasks in both forms
     for n, shards in ((6144, 1), (6144, 8), (5000, 4)):
         assert lam.symv_plan_check(n, shards, dtype)[:2] == (0, 0)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("LAM_RUN_SLOW"), reason="set LAM_RUN_SLOW=1 (minutes of CPU, 4 GiB of memory); its output is committed as "
+                                                                 "profiles/r05_symv_plan_full_size.txt")
+def test_symmetric_product_plan_at_the_advertised_sizes(lam):
+    """The plan the symmetric product runs on where it is advertised (README: N = 65536 fp64 on one GPU and on 8 row shards,
+    N = 131072 fp32): from N = 65536 on the planner switches to 2048-row bulk tasks, a shape no smaller case builds.  The exhaustive
+    check (lam_hip_debug_symv_plan, two bitmaps of n^2 / 8 bytes) must report every directed pair exactly once and nothing unused
+    in an interior task.  Run once per change of the planner with LAM_RUN_SLOW=1; the table it prints is committed under profiles/."""
+    import time
+    rows = []
+    for n, shards, dtype, name in ((65536, 1, 0, "fp64"), (65536, 8, 0, "fp64"), (65536, 2, 0, "fp64"), (65536, 4, 0, "fp64"), (131072, 1, 1, "fp32"),
+                                   (131072, 8, 1, "fp32"), (131072, 1, 2, "bf16"), (50000, 6, 0, "fp64")):
+        t0 = time.time()
+        bad_pairs, bad_interior, tasks = lam.symv_plan_check(n, shards, dtype)
+        rows.append(f"N={n:6d} {name} shards={shards}: tasks {tasks:7d}  pairs not made exactly once {bad_pairs}  bad interior elements {bad_interior}  "
+                    f"({n * n:.3e} directed pairs walked in {time.time() - t0:.0f} s)")
+        print(rows[-1], flush=True)
+        assert (bad_pairs, bad_interior) == (0, 0) and tasks > 0, rows[-1]
+    out = os.environ.get("LAM_SLOW_OUT")
+    if out:
+        with open(out, "w") as f:
+            f.write("# tests/test_capi_cpu.py::test_symmetric_product_plan_at_the_advertised_sizes (LAM_RUN_SLOW=1): lam_hip_debug_symv_plan, host only\n")
+            f.write("\n".join(rows) + "\n")

@@ -534,3 +534,33 @@ def test_reference_file_grid_sizes(tmp_path, symmetric):
         f = x["csv"].split(",")
         assert x["match"] and len(f) == 10 and f[0] == str(x["n"]) and f[1] == "1" and float(f[8]) < 1e-9 and float(f[5]) > 0
         assert 0.97 * 358 <= x["iters"] <= 1.03 * 360, x
+
+def test_reference_scaling_grids_at_reduced_size(tmp_path, mock_async):
+    """tools/sweep.py --grid scaling: the reference's strong-scaling (N = 20000 / 40000 / 50000 at P = 1, 2, 3, 4, 6, 8 --
+    TESTS/results/STRONG_SCALABILITY_GPU_MPI.txt:15-43; P = 3 and 6 are its uneven partition) and weak-scaling series
+    (WEAK_SCALABILITY_GPU_MPI.txt:15-17) at a tenth of the sizes on ONE device: through the one-process driver (`-P shards`, all
+    shards on GPU 0) for every P, and through `mpiexec -n P` on the MPI-bootstrapped driver (ranks on the stream-ordered RCCL
+    double) up to 4 ranks.  Every line must land on the reference's iteration count for its generator's law (358-360, +-3 %) at
+    tolerance 1e-9; speed-ups are reported next to the reference's published ones, not gated (one device).  The full command for
+    an 8-GPU node is in README.md."""
+    import json
+    js, csv = tmp_path / "scaling.json", tmp_path / "scaling.csv"
+    have_mpi = os.path.exists(os.path.join(TEST_DIR, "test_CG_MultiGPUS_HIP_RCCL_mpi.out")) and os.path.exists("/opt/conda/bin/mpiexec")
+    cmd = [sys.executable, SWEEP, "--grid", "scaling", "--scale", "0.1", "--json", str(js), "--csv", str(csv), "--launcher", "both" if have_mpi else "one-process",
+           "--preload", mock_async, "--max-ranks", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, LAM_HIP_QUIET_RCCL="1"))
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    recs = json.load(open(js))
+    one = [x for x in recs if x["topology"] == "one-process"]
+    assert [(x["n_reference"], x["procs"]) for x in one if x["grid"] == "strong"] == [(n, p) for n in (20000, 40000, 50000) for p in (1, 2, 3, 4, 6, 8)]
+    assert [(x["n_reference"], x["procs"]) for x in one if x["grid"] == "weak"] == [(10000, 1), (20000, 4), (40000, 8)]
+    assert all(x["match"] and (347 if x["n"] >= 4000 else 333) <= x["iters"] <= 371 and float(x["err"]) < 1e-9 for x in recs), [x for x in recs if not x["match"]]
+    assert all(x["speedup_iter"] > 0 and x["reference"]["speedup_iter_vs_p1"] > 0 for x in one if x["grid"] == "strong")
+    if have_mpi:
+        mpi = [x for x in recs if x["topology"] == "mpiexec"]
+        assert {x["procs"] for x in mpi} == {1, 2, 3, 4} and len(mpi) == 3 * 4 + 2
+        # same systems, same partition: both topologies land on the same count to the summation order (+-3)
+        for x in mpi:
+            y = next(z for z in one if (z["grid"], z["n"], z["procs"]) == (x["grid"], x["n"], x["procs"]))
+            assert abs(x["iters"] - y["iters"]) <= 3, (x, y)
+    assert open(csv).read().splitlines()[0].startswith("topology,N,procs,")

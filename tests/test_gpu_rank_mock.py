@@ -28,7 +28,7 @@ MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
 
 def ITER_GATE(ref_iters):      # noqa: N802
     """max(3, 2 %): the HIP path lands -3 ... 0 iterations from the reference's own counts over 45 fixture x topology runs
-    (profiles/r04_parity_margins.txt: 181 against 184 on the n=128 fixture), so SURVEY 8c's max(2, 1 %) would fail it; the
+    (profiles/r05_parity_margins.txt: 181 against 184 on the n=128 fixture), so SURVEY 8c's max(2, 1 %) would fail it; the
     reference algorithm moves by as much under a different reduction order alone (oracle with 2-8 threads / 2-5 ranks)."""
     return max(3, 0.02 * ref_iters)
 

@@ -120,7 +120,7 @@ def test_heat_cg_file_mode_config5(lam, oracle, tmp_path):
     x_or, st_or = oracle.cg_solve(np.asarray(A), b, 10000, 1e-9, threads=16)
     assert st_or["converged"]
     # iteration gate: max(3, 2 %) -- what the HIP path measures against the reference's own fixtures (-3 ... 0 over 45
-    # fixture x topology runs, profiles/r04_parity_margins.txt; SURVEY 8c's max(2, 1 %) would fail the 181-vs-184 case)
+    # fixture x topology runs, profiles/r05_parity_margins.txt; SURVEY 8c's max(2, 1 %) would fail the 181-vs-184 case)
     assert abs(int(f[7]) - st_or["num_iters"]) <= max(3, 0.02 * st_or["num_iters"])
     # solution: both x solve the system only to their residuals, x - x_or = A^-1 (r_or - r), so
     # ||x - x_or|| <= (||r|| + ||r_or||) / lambda_min -- rigorous; lambda_min of the 5-point Laplacian on the m x m interior

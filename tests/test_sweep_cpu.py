@@ -55,3 +55,46 @@ def test_sweep_accepts_the_closed_form_and_rejects_a_wrong_digit(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "MISMATCH" in r.stdout
     assert not any(x["match"] for x in json.load(open(js)))
+
+
+FAKE_SCALING = r'''#!/usr/bin/env python3
+import sys
+a = sys.argv[1:]
+n = int(a[a.index("-s") + 1]); P = int(a[a.index("-P") + 1]) if "-P" in a else 1
+assert "-R" in a and "-g" in a
+t_iter = 1e-3 * (n / 1000.0) ** 2 / P + 2e-5          # a made-up machine that scales
+print(f"{n},{P},1,0.5,0,{t_iter * 0.9:.6g},{t_iter:.6g},{359 + WRONG},9.5e-10,{t_iter * 359:.6g}")
+'''
+
+
+def test_scaling_grids_have_the_reference_procs_axis(tmp_path):
+    """--grid strong / weak without a GPU: the (N, P) points are the reference's (STRONG_SCALABILITY_GPU_MPI.txt: N = 20000 / 40000 /
+    50000 at 1, 2, 3, 4, 6, 8 devices; WEAK: (10000, 1), (20000, 4), (40000, 8)), every line carries this run's speed-up over its own
+    P = 1 line next to the reference's published one with its source line, the iteration count is held to the reference's, and a
+    wrong count fails the sweep."""
+    g = json.load(open(os.path.join(GOLDEN, "reference_scaling.json")))
+    assert [(e["n"], e["procs"]) for e in g["strong"][:8]] == [(20000, p) for p in (1, 2, 3, 4, 6, 8, 12, 16)]
+    assert g["strong"][2]["source"] == "TESTS/results/STRONG_SCALABILITY_GPU_MPI.txt:18" and g["strong"][2]["speedup_cg_vs_p1"] == 2.293
+    assert [(e["n"], e["procs"], e["iters"]) for e in g["weak"][:3]] == [(10000, 1, 358), (20000, 4, 359), (40000, 8, 360)]
+
+    def fake(wrong):
+        exe = tmp_path / f"fake_scaling_{wrong}.py"
+        exe.write_text(FAKE_SCALING.replace("WRONG", str(wrong)))
+        exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+        return str(exe)
+
+    js, csv = tmp_path / "s.json", tmp_path / "s.csv"
+    r = subprocess.run([sys.executable, SWEEP, "--grid", "scaling", "--exe", fake(0), "--json", str(js), "--csv", str(csv)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = json.load(open(js))
+    strong, weak = [x for x in recs if x["grid"] == "strong"], [x for x in recs if x["grid"] == "weak"]
+    assert [(x["n"], x["procs"]) for x in strong] == [(n, p) for n in (20000, 40000, 50000) for p in (1, 2, 3, 4, 6, 8)]
+    assert [(x["n"], x["procs"]) for x in weak] == [(10000, 1), (20000, 4), (40000, 8)]
+    assert all(x["match"] and x["topology"] == "one-process" for x in recs)
+    s8 = next(x for x in strong if (x["n"], x["procs"]) == (40000, 8))
+    assert 7.5 < s8["speedup_iter"] < 8.0 and s8["reference"]["speedup_cg_vs_p1"] == 5.32 and s8["reference"]["source"].endswith(":31")
+    lines = open(csv).read().splitlines()
+    assert lines[0].startswith("topology,N,procs,threads,") and lines[0].endswith("reference_speedup_iter,reference_speedup_cg,reference_source")
+    assert len(lines) == 1 + 18 + 3 and lines[1].startswith("one-process,20000,1,1,")
+    r = subprocess.run([sys.executable, SWEEP, "--grid", "weak", "--exe", fake(40), "--json", str(js)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "MISMATCH" in r.stdout
