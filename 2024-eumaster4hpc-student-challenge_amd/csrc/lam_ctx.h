@@ -19,6 +19,12 @@ uint64_t thread_cpu_ns()
 }
 
 constexpr int kLag = 4;          // iterations the host may run ahead of the stop flag
+// Default exchange of new contexts, ONE LINE EACH to flip once a run on separate GPUs has priced the collectives (bench.py records
+// every exchange of both topologies under exchange_modes).  Gather-Ap in both since round 5: one collective / one event join per
+// iteration instead of three, two launches instead of three, everything on one stream -- 620 + L' against 644 + 2 L us per iteration
+// at P = 8 by the one-GPU model, 3 x the iteration rate on the stream-ordered RCCL double.
+constexpr int64_t kRankModeDefaultExchange = 1;      // lam_hip_create_rank (round 4: 0)
+constexpr int64_t kOneProcessDefaultExchange = 1;    // lam_hip_create with several shards
 constexpr int kVecBlocksMax = 256;
 
 struct ShardBase {

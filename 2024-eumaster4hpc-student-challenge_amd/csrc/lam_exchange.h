@@ -100,10 +100,8 @@ int create_common(lam_hip_ctx *c)
         const int64_t before = c->opt_symmetric;
         c->opt_symmetric = symmetric_from_env(c->opt_symmetric);
         c->symmetric_from_env = c->opt_symmetric != before || (getenv("LAM_HIP_SYMMETRIC") != nullptr && c->opt_symmetric != 0);
-        // rank mode runs the symmetric product on the gather-Ap exchange only: a driver that asks for one through the environment
-        // gets the other with it, unless it chose an exchange itself
-        const char *ex = getenv("LAM_HIP_EXCHANGE");
-        if (c->symmetric_from_env && c->rank_mode && (ex == nullptr || *ex == '\0')) c->opt_exchange = 1;
+        // (several shards / ranks run the symmetric product on the gather-Ap exchange only -- the default of both topologies; with
+        // LAM_HIP_EXCHANGE=0 the option is not effective and env_symmetric_check says so)
     }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

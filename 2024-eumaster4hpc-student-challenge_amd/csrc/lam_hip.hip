@@ -96,7 +96,7 @@ int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device
     // three (host time to enqueue an iteration at 8 shards 0.15 ms against 0.59 ms, profiles/r04_host_enqueue_cost.txt),
     // same HIP-guaranteed ordering; sizes it cannot take (N % shards != 0) run on exchange 0 ("exchange_effective" tells).
     // The join goes through shard 0's stream when there are more than two shards (2(P-1)+1 runtime calls instead of P(P-1)).
-    if (n_shards > 1) c->opt_exchange = 1;
+    if (n_shards > 1) c->opt_exchange = kOneProcessDefaultExchange;
     c->opt_join = n_shards > 2 ? 1 : 0;
     c->opt_exchange = exchange_from_env(c->opt_exchange);
     int rc = create_common(c.get());
@@ -134,7 +134,7 @@ int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int device_id, int rank, i
     const char *force = getenv("LAM_HIP_FORCE_RCCL");
     const bool forced = force && *force && strcmp(force, "0") != 0;
     c->rank_mode = nranks > 1 || forced;
-    c->opt_exchange = exchange_from_env(c->opt_exchange);   // default exchange for this context
+    c->opt_exchange = exchange_from_env(kRankModeDefaultExchange);   // default exchange for this context
     c->sh.resize(1);
     c->sh[0].index = rank;
     c->sh[0].dev = device_id;

@@ -422,9 +422,11 @@ def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
     s = lam.Solver(lam.F64, rank=rank, nranks=world, device_id=rdzv.local_rank % max(1, ndev), unique_id=uid)
     try:
         s.set_option("gemv_timing", args.gemv_timing)
-        rec = {"n_gpus": world, "rccl_version": lam.rccl_version(), "rccl_ranks": s.get_option("rccl_ranks"), "rccl_init_s": None,
-               "parallelism": f"row-sharded x{world}, 1 process/GPU, RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration"}
         default_exchange = s.get_option("exchange")
+        what = {0: "RCCL all-gather x2 (8 B/rank) + all-gather(p) per iteration", 1: "ONE RCCL all-gather of [Ap slice | p.Ap part] per iteration (gather-Ap)",
+                2: "direct stores into peer-mapped mailboxes"}.get(default_exchange, f"exchange {default_exchange}")
+        rec = {"n_gpus": world, "rccl_version": lam.rccl_version(), "rccl_ranks": s.get_option("rccl_ranks"), "rccl_init_s": None,
+               "parallelism": f"row-sharded x{world}, 1 process/GPU, {what}"}
         if part == "main":
             host_ns0 = s.get_option("host_enqueue_ns")
             st, dt = run_config(s, n, args.warmup, args.steps, barrier, ramp_s=args.ramp if leg_name is None else min(args.ramp, 0.3))
@@ -456,10 +458,9 @@ def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
             if world > 1 or os.environ.get("LAM_HIP_FORCE_RCCL", "0") not in ("", "0"):
                 # Same problem, same context, the other exchanges of the rank mode (all product paths under the same parity
                 # tests) -- recorded for comparison, never the headline.
-                if default_exchange == 0:
-                    timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0)
-                else:
+                if default_exchange != 0:
                     timed("allgather_x2+allgather_p", exchange=0, overlap=1)
+                timed("allgather_x2+allgather_p, no overlap", exchange=0, overlap=0)
                 if default_exchange != 1:
                     timed("allgather_Ap", exchange=1, overlap=1)
                 # the opt-in symmetric product on row shards (every pair {i, j} read once, cyclic half windows; each rank gathers the

@@ -42,8 +42,8 @@ extern "C" {
  *      shards" (was: one shard, N a multiple of 4096).
  *   4  (round 5) lam_hip_stats grows by t_exchange (appended: the older fields keep their offsets, but a caller must pass
  *      the larger struct); BEHAVIOUR: the gather-Ap exchange takes any N >= shards (the reference's uneven partition), so
- *      "exchange_effective" no longer drops to 0 for N % shards != 0; LAM_HIP_SYMMETRIC also selects exchange 1 in rank
- *      mode when LAM_HIP_EXCHANGE is unset. */
+ *      "exchange_effective" no longer drops to 0 for N % shards != 0; lam_hip_create_rank defaults to the gather-Ap
+ *      exchange too (option "exchange" = 1; was 0). */
 #define LAM_HIP_ABI_VERSION 4
 
 /* storage / arithmetic type of the matrix and vectors */
@@ -245,8 +245,8 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  * enqueue threads, hub join, separate reduction launches, MFMA-fed GEMV, 19 GEMV tuning shapes) exist only in
  * liblam_hip_tuning.so and are described in include/lam_hip_tuning.md -- this library refuses to switch them on.
  *
- *   "exchange"      how row shards exchange per iteration.  Default 1 for lam_hip_create with several shards, 0 for
- *                   lam_hip_create_rank; environment LAM_HIP_EXCHANGE sets the default of new contexts.
+ *   "exchange"      how row shards exchange per iteration.  Default 1 in both multi-GPU topologies (rank mode: 0 until round
+ *                   4); environment LAM_HIP_EXCHANGE sets the default of new contexts.
  *                     1  gather-Ap: ONE exchange of [Ap slice | p.Ap part] per iteration (one ncclAllGather / one event
  *                        join), r and p full-length on every shard (the reference CPU path's layout, CPU_MPI_OMP.hpp:476,505).
  *                        Any N >= shards: records hold the longest slice of the reference's uneven partition (:176-196).

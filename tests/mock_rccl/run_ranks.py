@@ -97,7 +97,8 @@ def main():
                 out[r] = dict(conv=conv, iters=s.stats["num_iters"], err=s.stats["rel_err"], x=x, res=res, y=y,
                               part=s.partition(r), ncoll=s.get_option("collectives_enqueued"), calls=calls,
                               eff=s.get_option("exchange_effective"), fallbacks=s.get_option("direct_fallbacks"),
-                              sym=s.get_option("symmetric_effective"), t_exchange=s.stats["t_exchange"], t_gemv=s.stats["t_gemv"])
+                              sym=s.get_option("symmetric_effective"), t_exchange=s.stats["t_exchange"], t_gemv=s.stats["t_gemv"],
+                              on_dev=s.get_option("ranks_on_device"), fused=s.get_option("fuse_effective"))
         except Exception as e:                   # noqa: BLE001
             errs.append(f"rank {r}: {e!r}")
 
@@ -121,6 +122,7 @@ def main():
         "exchange_effective": [o["eff"] for o in out], "direct_fallbacks": [o["fallbacks"] for o in out],
         "symmetric_effective": [o["sym"] for o in out], "x_sha": hashlib.sha256(out[0]["x"].tobytes()).hexdigest(),
         "t_exchange": [o["t_exchange"] for o in out], "t_gemv": [o["t_gemv"] for o in out],
+        "ranks_on_device": [o["on_dev"] for o in out], "fuse_effective": [o["fused"] for o in out],
         "ranks_identical": bool(all(np.array_equal(out[0]["x"], o["x"]) and o["iters"] == out[0]["iters"]
                                     and o["err"] == out[0]["err"] and np.array_equal(out[0]["y"], o["y"]) for o in out)),
     }

@@ -124,6 +124,8 @@ def test_rank_mode_collectives_single_rank(lam, oracle, monkeypatch):
         x0, st0 = s.solution(), s.stats
     monkeypatch.setenv("LAM_HIP_FORCE_RCCL", "1")
     with lam.Solver(lam.F64, rank=0, nranks=1, device_id=0, unique_id=None) as s:
+        assert s.get_option("exchange") == 1          # the rank mode's default: gather-Ap (round 5)
+        s.set_option("exchange", 0)                   # the sliced-vector exchange sums in the single-shard order: same bits
         s.set_matrix(A); s.set_rhs(b); s.solve(500, 1e-10)
         x1, st1 = s.solution(), s.stats
         assert st1["t_comm_init"] > 0
@@ -236,7 +238,7 @@ def test_mpi_bootstrapped_driver_multi_rank(tmp_path, mock_mp_lib, mock_async, n
         assert len(lines) == nranks and all(l["abort"] == 0 for l in lines) and len({l["calls"] for l in lines}) == 1, lines
 
 
-@pytest.mark.parametrize("exchange", ["1", "2", "1+symmetric"])
+@pytest.mark.parametrize("exchange", ["0", "1", "2", "1+symmetric"])
 def test_mpi_driver_other_exchanges_across_processes(tmp_path, mock_async, exchange):
     """LAM_HIP_EXCHANGE=1 (one all-gather per iteration) and =2 (direct: p replicas and mailboxes of the other
     PROCESSES mapped through HIP IPC, no collective inside the iteration) under `mpiexec -n 4`, run to

@@ -416,9 +416,12 @@ def test_parity_margins_are_inside_the_gates(mock_async):
 
 # the gates of the fp32 file-mode test below, and what they come from: the maxima of profiles/r05_parity_margins_f32.txt (40 runs:
 # four fixtures of the reference's own float class x one shard / 2-3 shards / 2 ranks on the RCCL double / the symmetric option)
-F32_GATES = {"iters_abs": 5, "iters_rel": 0.04, "x_converged": 3e-4, "residual_over_tol": 2.0, "x_5_iterations": 4e-6, "rel_err_5_iterations": 4e-5,
-             "x_40_iterations": 5e-4, "rel_err_40_iterations": 4e-2}
-BF16_GATES = {"iters_abs": 3, "iters_rel": 0.03, "x": 2e-3, "residual_over_tol": 4.0}
+# measured maxima (round 5): converged fixtures |d iters| 4 of 139 (2.9 %), |x - x_ref| / |x_ref| 2.6e-6, fp64 residual of the fp32 x 2.6 x tol;
+# 5 fixed iterations: x 1.2e-6, printed residual off by 9.5e-7; 40 fixed iterations (cond ~ 1e3, fp32): x 2.9e-4, printed residual off by 9.2 %
+F32_GATES = {"iters_abs": 6, "iters_rel": 0.045, "x_converged": 5e-6, "residual_over_tol": 4.0, "x_5_iterations": 2e-6, "rel_err_5_iterations": 2e-6,
+             "x_40_iterations": 5e-4, "rel_err_40_iterations": 0.14}
+# bf16 storage against the oracles on the bf16-rounded matrix (iterations: the fp32 oracle; x: the fp64 oracle)
+BF16_GATES = {"iters_abs": 6, "iters_rel": 0.06, "x": 3e-5, "residual_over_tol": 4.0}
 
 
 def test_low_precision_margins_are_inside_the_gates(mock_async):

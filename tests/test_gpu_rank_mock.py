@@ -113,6 +113,9 @@ def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, ov
     _check_solution(out, P, n, mode)
     if exchange == 1:
         assert out["exchange_effective"] == [1] * P, out      # any N >= P: no fallback (round 5)
+    # the ranks count who shares their GPU once at creation (here: all P of them), so that the fused vector step --
+    # whose workgroups wait for each other -- is used only when the launches of ALL ranks on the device are resident together
+    assert out["ranks_on_device"] == [P] * P and len(set(out["fuse_effective"])) == 1, out
     # lam_hip_stats.t_exchange: the collectives of exchanges 0 / 1 are bracketed with HIP events on every rank (sampled with the
     # GEMV timing); the direct exchange waits inside its kernels and reports none
     if not (out["direct_fallbacks"][0] if exchange == 2 else 0):
@@ -345,9 +348,9 @@ def _check_bench_line(r, nproc):
     for m in modes.values():
         assert m.get("value", 0) > 0 and "error" not in m, out["exchange_modes"]
     # the headline is the product's DEFAULT exchange, whatever the others measured (never a minimum over variants)
-    assert out["exchange_modes"]["default"] == "allgather_x2+allgather_p"
-    assert out["value"] == modes["allgather_x2+allgather_p"]["value"]
-    assert "RCCL all-gather x2" in out["config"]["parallelism"]
+    assert out["exchange_modes"]["default"] == "allgather_Ap"           # gather-Ap: the rank mode's default since round 5
+    assert out["value"] == modes["allgather_Ap"]["value"]
+    assert "ONE RCCL all-gather" in out["config"]["parallelism"] and out["exchange_effective"] == 1
     # ... and it checked itself: true == recursive residual, and the same residual as the one-GPU solve of the system
     sc = out["self_check"]
     assert sc["passed"] and sc["true_vs_recursive"] < 1e-6 and sc["vs_one_gpu"] < 1e-9, sc

@@ -54,7 +54,9 @@ def f32_table(lam, golden, out_path):
     have_mock = os.path.exists(MOCK)
 
     def record(g, topo, iters, rel_err, x, A, b, x_ref):
-        d = iters - g["iters_printed"]
+        # (a run that stops at the iteration cap: the reference's float harness prints max_iters, lam_hip_stats the loop counter on
+        # exit, max_iters + 1 -- the same iteration)
+        d = iters - g["iters_printed"] - (0 if g["converged"] else 1)
         xe = float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref))
         res = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
         rr = abs(rel_err / g["rel_err_printed"] - 1)
