@@ -674,6 +674,11 @@ def public(rec):
 
 def leg_main(args):
     """Child-process mode: run one leg and leave its record in --leg-out (rank 0 of the leg writes it)."""
+    try:        # a leg lives in a session of its own (so that its parent can kill all of it): make sure it also DIES with its parent
+        import ctypes
+        ctypes.CDLL(None).prctl(1, signal.SIGKILL)          # PR_SET_PDEATHSIG
+    except Exception:   # noqa: BLE001
+        pass
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
