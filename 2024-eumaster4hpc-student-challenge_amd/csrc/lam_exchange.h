@@ -35,18 +35,26 @@ int64_t symmetric_from_env(int64_t dflt)
     return (k >= 0 && k <= 2) ? k : dflt;
 }
 
-// max |A - A^T| and max |A| of a single-shard context's matrix (one tiled pass over the upper triangle and its mirror image)
+// max |A - A^T| and max |A| of the matrix a single-PROCESS context holds (one tiled pass over the upper triangle and its mirror
+// image; with several shards shard 0's device reads the other shards' rows through peer access)
 int measure_asymmetry(lam_hip_ctx *c, double *max_asym, double *max_abs)
 {
     return dispatch(c, [&](auto impl) -> int {
         using TA = typename ImplTraits<decltype(impl)>::TA;
+        for (auto &t : c->sh) {                      // the generators / uploads of every shard are done
+            LAMCHK(set_dev(c, t));
+            HIPCHK(c, hipStreamSynchronize(t.stream));
+        }
         ShardBase &s = c->sh[0];
         LAMCHK(set_dev(c, s));
+        PtrList shards;
+        shards.n = (int)c->sh.size();
+        for (int q = 0; q < shards.n; q++) shards.p[q] = c->sh[q].A;
         const int grid = 2048;
         DevBuf outb;
         HIPCHK(c, hipMalloc(&outb.p, sizeof(double) * 2 * grid));
         std::vector<double> h(2 * grid);
-        hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, (const TA *)s.A, c->lda, c->n, outb.as<double>());
+        hipLaunchKernelGGL((asymmetry_kernel<TA>), dim3(grid), dim3(kBlock), 0, s.stream, shards, c->n / (uint64_t)c->total_shards, c->lda, c->n, outb.as<double>());
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(h.data(), outb.p, sizeof(double) * 2 * grid, hipMemcpyDeviceToHost, s.stream));
         HIPCHK(c, hipStreamSynchronize(s.stream));
@@ -61,11 +69,12 @@ int measure_asymmetry(lam_hip_ctx *c, double *max_asym, double *max_abs)
 // Option "symmetric" asked for through the ENVIRONMENT (a driver that cannot call lam_hip_set_option or lam_hip_check_symmetry,
 // e.g. the reference's own driver sources compiled against these headers): the library vouches for the precondition itself.
 //   * not effective (rank mode / several shards on an exchange other than gather-Ap): said once on stderr, the general GEMV runs;
-//   * one shard: A is compared with its transpose once per matrix (one pass over A).  Equal bit for bit: nothing to say.
+//   * one process (one shard or several): A is compared with its transpose once per matrix (one pass over A; the rows of other
+//     shards through peer access).  Equal bit for bit: nothing to say.
 //     Unequal at rounding level (<= 64 ulp of the largest element: a file written by a generator that rounds A_ij and A_ji
 //     separately, like the reference's MKL-based one): a warning -- the upper triangle then DEFINES the system that is solved.
 //     More: refused, the general GEMV runs (and says so);
-//   * several shards: the transpose lives on other devices -- not checked, the caller vouches as with the option.
+//   * rank mode: the transpose lives in other processes -- not checked, the caller vouches as with the option.
 int env_symmetric_check(lam_hip_ctx *c)
 {
     if (!c->symmetric_from_env || c->opt_symmetric == 0) return 0;
@@ -77,7 +86,8 @@ int env_symmetric_check(lam_hip_ctx *c)
         c->told_sym_ineffective = true;       // once per context
         return 0;
     }
-    if (!c->symv_active() || c->sym_checked_gen == c->matrix_gen) return 0;
+    if (!c->symv_active() && !c->symv_multi_active()) return 0;           // not asked for at this size
+    if (c->rank_mode || c->sym_checked_gen == c->matrix_gen) return 0;     // rank mode: the transpose lives in other processes
     double asym = 0.0, amax = 0.0;
     LAMCHK(measure_asymmetry(c, &asym, &amax));
     c->sym_checked_gen = c->matrix_gen;

@@ -944,7 +944,7 @@ int lam_hip_check_symmetry(lam_hip_ctx *c, double *max_abs_asymmetry)
 {
     if (!c || !max_abs_asymmetry) return LAM_HIP_EINVAL;
     if (!c->have_matrix) return fail(c, LAM_HIP_ESTATE, "matrix not set");
-    if (c->rank_mode || c->total_shards != 1) return fail(c, LAM_HIP_EINVAL, "symmetry check needs the whole matrix on one shard");
+    if (c->rank_mode) return fail(c, LAM_HIP_EINVAL, "symmetry check needs the whole matrix in one process");
     double max_abs = 0.0;
     return measure_asymmetry(c, max_abs_asymmetry, &max_abs);
 }

@@ -1377,10 +1377,17 @@ symv_reduce_kernel(const T *__restrict__ rowpart, const T *__restrict__ colpart,
 __device__ __forceinline__ double elem_as_double(double v) { return v; }
 __device__ __forceinline__ double elem_as_double(float v) { return (double)v; }
 __device__ __forceinline__ double elem_as_double(__hip_bfloat16 v) { return (double)__uint_as_float(((unsigned)*reinterpret_cast<const unsigned short *>(&v)) << 16); }
+// Several row shards of ONE process (`shards.n` > 1): row i lives in shard min(i / base_rows, shards.n - 1) (the reference's
+// partition), whose matrix the launching device reads through peer access -- one-off, at the speed of the links.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-asymmetry_kernel(const T *__restrict__ A, uint64_t lda, uint64_t n, double *__restrict__ out)
+asymmetry_kernel(PtrList shards, uint64_t base_rows, uint64_t lda, uint64_t n, double *__restrict__ out)
 {
+    auto elem = [&](uint64_t i, uint64_t j) -> double {
+        uint64_t q = shards.n > 1 ? i / base_rows : 0;
+        if (q >= (uint64_t)shards.n) q = (uint64_t)shards.n - 1;
+        return elem_as_double(static_cast<const T *>(shards.p[q])[(i - q * base_rows) * lda + j]);
+    };
     constexpr int TS = 32;
     __shared__ double s_up[TS][TS + 1], s_lo[TS][TS + 1];
     __shared__ double s_max[2][kWaves];
@@ -1397,8 +1404,8 @@ asymmetry_kernel(const T *__restrict__ A, uint64_t lda, uint64_t n, double *__re
         for (int r = ty; r < TS; r += kBlock / TS) {
             const uint64_t iu = bi * TS + r, ju = bj * TS + tx;       // element (iu, ju) of the upper tile
             const uint64_t il = bj * TS + r, jl = bi * TS + tx;       // element (il, jl) of its mirror image
-            s_up[r][tx] = (iu < n && ju < n) ? elem_as_double(A[iu * lda + ju]) : 0.0;
-            s_lo[r][tx] = (il < n && jl < n) ? elem_as_double(A[il * lda + jl]) : 0.0;
+            s_up[r][tx] = (iu < n && ju < n) ? elem(iu, ju) : 0.0;
+            s_lo[r][tx] = (il < n && jl < n) ? elem(il, jl) : 0.0;
         }
         __syncthreads();
         for (int r = ty; r < TS; r += kBlock / TS) {

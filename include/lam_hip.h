@@ -211,8 +211,8 @@ int lam_hip_dot(lam_hip_ctx *ctx, const void *x_host, const void *y_host, uint64
 int lam_hip_axpby(lam_hip_ctx *ctx, double alpha, const void *x_host, double beta, void *y_host,
                   uint64_t n);
 
-/* max |A[i][j] - A[j][i]| of the matrix held by a single-shard context (fp64/fp32 storage): lets a caller
- * verify the precondition of option "symmetric".  No reference counterpart. */
+/* max |A[i][j] - A[j][i]| of the matrix held by a single-PROCESS context (one shard or several; every storage type): lets a
+ * caller verify the precondition of option "symmetric".  No reference counterpart. */
 int lam_hip_check_symmetry(lam_hip_ctx *ctx, double *max_abs_asymmetry);
 
 /* Host-only check of the symmetric product's PLAN (no device needed, no context): builds the task lists of all `shards` row shards
@@ -266,9 +266,9 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *                   One shard: the upper triangle; several (exchange 1): cyclic half windows per row, each shard contributes
  *                   a full-length vector to the exchange.  1 = where it pays (from 192 MiB of matrix on), 2 = always, 0
  *                   (default) = the reference's general GEMV.  Same results to rounding.  "symmetric_effective" (get).
- *                   Environment LAM_HIP_SYMMETRIC = 1 | 2 (drivers): the library then checks A = A^T itself once per matrix on
- *                   one shard (warns at rounding level, refuses beyond), selects exchange 1 in rank mode unless
- *                   LAM_HIP_EXCHANGE is set, and says on stderr when the option is not effective.
+ *                   Environment LAM_HIP_SYMMETRIC = 1 | 2 (drivers): the library then checks A = A^T itself once per matrix
+ *                   (one process; warns at rounding level, refuses beyond; rank mode: unchecked) and says on stderr when the
+ *                   option is not effective (several shards / ranks on an exchange other than 1).
  *   "fuse_update"   1 (default) = the x, r, p updates of an iteration are ONE launch (r.r handed over inside the launch):
  *                   2 launches per shard and iteration.  Used only when the whole grid of all shards / ranks on the device
  *                   is resident ("fuse_effective" tells; "assume_cus" overrides the CU count for tests).  Same bits.

@@ -783,6 +783,7 @@ def test_symmetric_option_preconditions(lam):
         assert abs(s.check_symmetry() - 0.25) < 1e-12
     with lam.Solver(lam.F64, n_shards=2, device_ids=[0, 0]) as s:
         s.generate_random_spd(4096, 5, 10.0)
+        assert s.check_symmetry() == 0.0                  # several shards of one process: checked through peer access (round 5)
         s.set_option("symmetric", 2)
         assert s.get_option("symmetric_effective") == 1   # several shards: on the gather-Ap exchange (the default) ...
         s.set_option("exchange", 0)
@@ -799,8 +800,8 @@ def test_symmetric_option_from_the_environment_checks_itself(lam, monkeypatch, c
     these headers) asks for the symmetric product.  The library then vouches for the precondition itself: on one shard
     it compares A with its transpose once per matrix -- equal: silent; equal to rounding (a file whose generator rounds A_ij and
     A_ji separately, like the reference's MKL-based one): a warning, the upper triangle defines the system; otherwise REFUSED, the
-    general GEMV runs and the answer is the general one.  In rank mode the variable also selects the gather-Ap exchange (the only
-    one the symmetric product runs on) unless LAM_HIP_EXCHANGE says otherwise."""
+    general GEMV runs and the answer is the general one.  The same with several row shards of one process (peer reads); in rank
+    mode the transpose lives in other processes and the caller vouches as with the option."""
     n = 1500
     dt = getattr(lam, dtype_name)
     eps = 2.0 ** -52 if dtype_name == "F64" else 2.0 ** -23
@@ -849,8 +850,24 @@ def test_symmetric_option_from_the_environment_checks_itself(lam, monkeypatch, c
         s.generate_random_rhs(6)
         s.solve(30, 0.0)
         assert np.array_equal(s.solution(), x_refused)
-    # rank mode (a 1-rank communicator on the real RCCL): the variable brings the gather-Ap exchange with it
+    # several row shards of one process (the positional multi-GPU driver with LAM_NUM_SHARDS): shard 0's device reads the other
+    # shards' rows through peer access, same three outcomes
     monkeypatch.setenv("LAM_HIP_SYMMETRIC", "2")
+    with lam.Solver(dt, device_ids=[0, 0, 0]) as s:
+        s.generate_random_spd(n, 5, 100.0)
+        s.generate_random_rhs(6)
+        assert s.check_symmetry() == 0.0
+        s.solve(30, 0.0)
+        assert s.get_option("symmetric_effective") == 1 and "LAM_HIP_SYMMETRIC" not in capfd.readouterr().err
+        rows = s.download_rows(1200, 1)                 # a row of the LAST shard against a column of the first
+        rows[0, 3] += 0.25
+        s.upload_rows(1200, rows)
+        assert abs(s.check_symmetry() - 0.25) < 1e-6
+        s.generate_random_rhs(6)
+        s.solve(30, 0.0)
+        assert s.get_option("symmetric_effective") == 0 and s.get_option("exchange_effective") == 1 and "refused" in capfd.readouterr().err
+        assert s.true_residual() > 0                    # (the general GEMV on the gather-Ap exchange solved it)
+    # rank mode (a 1-rank communicator on the real RCCL): gather-Ap is its default exchange, so the option is effective
     monkeypatch.setenv("LAM_HIP_FORCE_RCCL", "1")
     with lam.Solver(dt, rank=0, nranks=1, device_id=0, unique_id=None) as s:
         assert s.get_option("exchange") == 1 and s.get_option("symmetric") == 2
