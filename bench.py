@@ -734,7 +734,7 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="matrix order of the CPU baseline sample (0 = the workload's own N: "
                     "no extrapolation; the reference driver needs 8*N^2 bytes of host memory)")
     ap.add_argument("--cpu-sample-iters", type=int, default=20)
-    ap.add_argument("--leg-timeout", type=float, default=240.0, help="seconds a child-process leg may take")
+    ap.add_argument("--leg-timeout", type=float, default=120.0, help="seconds a child-process leg may take (a healthy one needs 10-40 s at N=65536)")
     ap.add_argument("--mfma-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--leg-out", default=None, help=argparse.SUPPRESS)
