@@ -112,6 +112,94 @@ def test_sharded_protocol_matches_reference_mpi_path(world, n, oracle, tmp_path)
     np.testing.assert_allclose(A @ x, b, atol=1e-7)
 
 
+def _gather_ap_worker(rank, world, port, n, max_iters, tol, outdir, parts, vec_dtype):
+    """The gather-Ap exchange (option exchange = 1, the default of both multi-GPU topologies since round 5) as a protocol: ONE
+    equal-count all-gather of byte records per iteration.  Record of rank q = room for the LONGEST slice (n // P + n % P values,
+    rank q < P-1 fills the first n // P), padded to 8 bytes, then the rank's part of p.Ap as a double at stride - 8
+    (csrc/lam_ctx.h ex1_stride_bytes; kernels: lam_kernels.h gathered_ap).  r and p are full-length on every rank and updated
+    redundantly (the reference CPU path's layout, ConjugateGradient_CPU_MPI_OMP.hpp:476,505), so r.r needs no exchange."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as o
+    vdt = np.dtype(vec_dtype)
+    row0, nrows = parts[rank]
+    base, maxrows = n // world, n // world + n % world
+    stride = (maxrows * vdt.itemsize + 7) // 8 * 8 + 8
+    A_loc = o.tridiag(n, row0, nrows).astype(vdt)
+    b = np.random.default_rng(5).uniform(-1, 1, n).astype(vdt)
+    sl = slice(row0, row0 + nrows)
+    x = np.zeros(nrows, dtype=vdt); r = b.copy(); p = b.copy()          # FULL r and p on every rank
+    bb = float(np.dot(b.astype(np.float64), b.astype(np.float64))); rr = bb
+    k = 1
+    while k <= max_iters:
+        Ap_loc = o.gemv(A_loc, p)
+        rec = np.zeros(stride, dtype=np.uint8)
+        rec[:nrows * vdt.itemsize] = Ap_loc.view(np.uint8)
+        rec[stride - 8:] = np.array([np.dot(p[sl].astype(np.float64), Ap_loc.astype(np.float64))]).view(np.uint8)
+        out = [torch.empty(stride, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(out, torch.from_numpy(rec))                      # the iteration's ONLY collective
+        recs = [t.numpy() for t in out]
+        pAp = 0.0
+        for q in range(world):                                           # rank order, the same on every rank
+            pAp += float(recs[q][stride - 8:].view(np.float64)[0])
+        Ap = np.empty(n, dtype=vdt)
+        for i0 in range(0, n, 97):                                       # element i lives in record min(i // base, P - 1)
+            for i in range(i0, min(i0 + 97, n)):
+                q = min(i // base, world - 1)
+                Ap[i] = recs[q][:maxrows * vdt.itemsize].view(vdt)[i - q * base]
+        alpha = vdt.type(rr / pAp)
+        x = o.axpby(alpha, p[sl], 1.0, x)
+        r = o.axpby(-alpha, Ap, 1.0, r)
+        rr_new = float(np.dot(r.astype(np.float64), r.astype(np.float64)))
+        beta = vdt.type(rr_new / rr)
+        rr = rr_new
+        if np.sqrt(rr / bb) < tol:
+            break
+        p = o.axpby(1.0, r, beta, p)
+        k += 1
+    xs = [None] * world
+    dist.all_gather_object(xs, x)
+    if rank == 0:
+        np.save(os.path.join(outdir, "x.npy"), np.concatenate(xs))
+        np.save(os.path.join(outdir, "meta.npy"), np.array([k, np.sqrt(rr / bb)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,vec_dtype,tol", [(2, 256, "float64", 1e-9), (3, 301, "float64", 1e-9), (4, 1001, "float64", 1e-9), (3, 301, "float32", 2e-4)])
+def test_gather_ap_protocol_with_the_reference_uneven_partition(world, n, vec_dtype, tol, oracle, tmp_path):
+    """world_size 2 / 3 / 4 gloo run of the gather-Ap record protocol, uneven partitions (301 = 100 + 100 + 101, 1001 = 250 x 3 + 251)
+    and a 4-byte vector type whose odd-length slice needs the 8-byte padding in front of the double: the solve must reproduce the
+    reference's MPI recurrence (oracle with the same number of emulated ranks) to the summation order."""
+    import importlib
+    import multiprocessing
+    lam = importlib.import_module(PKG_NAME)
+    parts = [lam.partition(n, world, q) for q in range(world)]
+    ctx = multiprocessing.get_context("spawn")
+    port = 29650 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_gather_ap_worker, args=(r, world, port, n, 10000, tol, str(tmp_path), parts, vec_dtype)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0, f"worker exit code {pr.exitcode}"
+    x = np.load(tmp_path / "x.npy").astype(np.float64)
+    k, err = np.load(tmp_path / "meta.npy")
+    A = oracle.tridiag(n)
+    b = np.random.default_rng(5).uniform(-1, 1, n)
+    x_emul, st_emul = oracle.cg_solve(A.astype(vec_dtype), b.astype(vec_dtype), 10000, tol, P=world)
+    assert err < tol and abs(int(k) - st_emul["num_iters"]) <= max(3, 0.05 * st_emul["num_iters"]), (k, st_emul)
+    if vec_dtype == "float64":
+        np.testing.assert_allclose(x, x_emul, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(A @ x, b, atol=1e-6)
+    else:
+        assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 10 * tol
+
+
 def test_partition_function_matches_reference_rule(lam, oracle):
     for n, P in [(1001, 4), (65536, 8), (7, 7), (513, 2), (10, 3)]:
         got = [lam.partition(n, P, q) for q in range(P)]
