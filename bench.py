@@ -363,6 +363,8 @@ def write_leg_record(path, rec):
 def mode_record(steps, dt_, st_, res_, **extra):
     rec = {"value": steps / dt_, "ms_per_step": dt_ / steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3, "exchange_us": st_["t_exchange"] * 1e6,
            "gemv_plus_comm_ms": (st_["t_gemv"] + st_["t_exchange"]) * 1e3, "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
+    if "t_exchange_min" in st_:
+        rec["exchange_us_min_over_ranks"] = st_["t_exchange_min"] * 1e6
     rec.update(extra)
     return rec
 
@@ -416,7 +418,12 @@ def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
     n = args.n
 
     def max_over_ranks(dt_, st_):
+        # the collective cannot complete before the SLOWEST rank has contributed: the rank whose GEMV ends last sees the collective's
+        # own latency, every other one that latency plus its wait for the last -- so the minimum over the ranks is the wire + launch
+        # latency L of DESIGN.md's model, the maximum is L + the ranks' skew (both are recorded)
+        t_min = -rdzv.max([-st_["t_exchange"]])[0]
         dt_, st_["t_gemv"], st_["t_exchange"] = rdzv.max([dt_, st_["t_gemv"], st_["t_exchange"]])
+        st_["t_exchange_min"] = t_min
         return dt_, st_
 
     s = lam.Solver(lam.F64, rank=rank, nranks=world, device_id=rdzv.local_rank % max(1, ndev), unique_id=uid)
@@ -995,6 +1002,7 @@ def main():
                    "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
         "gemv_ms": st["t_gemv"] * 1e3,
         **({"exchange_us": st["t_exchange"] * 1e6, "gemv_plus_comm_ms": (st["t_gemv"] + st["t_exchange"]) * 1e3} if n_gpus > 1 or use_dist else {}),
+        **({"exchange_us_min_over_ranks": st["t_exchange_min"] * 1e6} if "t_exchange_min" in st else {}),
         **({"exchange_effective": effective_exchange} if effective_exchange is not None else {}),
         "other_us": (ms_per_step - st["t_gemv"] * 1e3) * 1e3,
         "host_enqueue_us_per_step": host_us_per_step,

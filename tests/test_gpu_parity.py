@@ -777,10 +777,17 @@ def test_symmetric_option_preconditions(lam):
         s.set_option("symmetric", 2)                      # value 2: at every size
         s.generate_random_spd(4096, 5, 10.0)
         assert s.get_option("symmetric_effective") == 1
-        rows = s.download_rows(7, 1)
+        orig = s.download_rows(7, 1)
+        rows = orig.copy()
         rows[0, 100] += 0.25                            # break the symmetry in one entry
         s.upload_rows(7, rows)
         assert abs(s.check_symmetry() - 0.25) < 1e-12
+        s.upload_rows(7, orig)
+        assert s.check_symmetry() == 0.0
+        rows = s.download_rows(4090, 1)                 # ... and one in the last tile row of the lower triangle (the tiled kernel's far corner)
+        rows[0, 4077] += 0.5
+        s.upload_rows(4090, rows)
+        assert abs(s.check_symmetry() - 0.5) < 1e-12
     with lam.Solver(lam.F64, n_shards=2, device_ids=[0, 0]) as s:
         s.generate_random_spd(4096, 5, 10.0)
         assert s.check_symmetry() == 0.0                  # several shards of one process: checked through peer access (round 5)

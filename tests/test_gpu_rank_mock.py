@@ -366,6 +366,7 @@ def _check_bench_line(r, nproc):
     # on the same line, measured by a child of rank 0 before any rank touched the GPU -- its experimental exchange in a child of its own
     assert out["host_plumbing"]["rccl_ranks"] == nproc and out["host_plumbing"]["rccl_calls_enqueued_rank0"] > 0
     assert out["exchange_us"] > 0 and out["gemv_plus_comm_ms"] > out["gemv_ms"]
+    assert 0 < out["exchange_us_min_over_ranks"] <= out["exchange_us"]          # min over ranks = the collective's own latency, max = + skew
     assert all(m["exchange_us"] > 0 for k, m in modes.items() if not k.startswith("direct")), modes
     op = out["one_process_topology"]
     assert "error" not in op and op["value"] > 0 and op["n_gpus"] == nproc and op["exchange_us"] > 0 and op["self_check"]["passed"], op
