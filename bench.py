@@ -555,11 +555,14 @@ def one_process_measure(lam, args, n_gpus, part, leg_name=None):
     n = args.n
     # LAM_BENCH_DEVICE_IDS="0,0" (tests on a one-GPU box): put the shards of the one-process topology on these devices
     dev_override = [int(x) for x in os.environ.get("LAM_BENCH_DEVICE_IDS", "").split(",") if x.strip() != ""]
-    device_ids = dev_override if len(dev_override) == n_gpus else list(range(n_gpus))
+    ndev = max(1, lam.device_count())
+    device_ids = dev_override if len(dev_override) == n_gpus else [q % ndev for q in range(n_gpus)]     # fewer devices than shards: shared (an emulation)
     s = lam.Solver(lam.F64, n_shards=n_gpus, device_ids=device_ids)
     try:
         s.set_option("gemv_timing", args.gemv_timing)
         rec = {"n_gpus": n_gpus, "parallelism": f"row-sharded x{n_gpus}, 1 process, direct xGMI peer stores ordered by HIP events", "device_ids": device_ids}
+        if len(set(device_ids)) < n_gpus:
+            rec["parallelism"] += f" -- EMULATION: {n_gpus} shards on {len(set(device_ids))} device(s), not a multi-GPU measurement"
         default_exchange, default_join = s.get_option("exchange"), s.get_option("exchange_join")
 
         def nobarrier():
@@ -823,7 +826,7 @@ def main():
         rdzv.barrier()
 
     # ---- this process's own topology ------------------------------------------------------------------------------------
-    exchange_modes, effective_exchange, rccl_info = None, None, None
+    exchange_modes, effective_exchange, rccl_info, shard_devices = None, None, None, None
     if use_dist:
         rec = rank_mode_measure(lam, args, rdzv, "main")
         st, dt, true_res, check, failures = rec["st"], rec["dt"], rec["true_res"], rec["self_check"], rec["failures"]
@@ -838,6 +841,7 @@ def main():
         kernel_name, cold_start, parallelism = rec["kernel"], rec["cold_start"], rec["parallelism"]
         host_us_per_step, effective_exchange = rec["host_enqueue_us_per_step"], rec["exchange_effective"]
         exchange_modes = rec["exchange_modes"]
+        shard_devices = rec["device_ids"]
         s = None
     else:
         s = lam.Solver(lam.F64)
@@ -999,7 +1003,7 @@ def main():
                    "untimed_setup": f"matrix generated on the device; {args.ramp} s of GEMV launches before the warm-up steps (waits out "
                                     "the driver's background wipe of the VRAM the child processes released: profiles/r04_bf16_gap_probe.txt; "
                                     "`value_cold` is the same measurement without it -- rounds 1-2 and BASELINE-style figures are cold)",
-                   "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus},
+                   "matrix_bytes_per_gpu": 8.0 * n * n / n_gpus, **({"shard_devices": shard_devices} if shard_devices else {})},
         "gemv_ms": st["t_gemv"] * 1e3,
         **({"exchange_us": st["t_exchange"] * 1e6, "gemv_plus_comm_ms": (st["t_gemv"] + st["t_exchange"]) * 1e3} if n_gpus > 1 or use_dist else {}),
         **({"exchange_us_min_over_ranks": st["t_exchange_min"] * 1e6} if "t_exchange_min" in st else {}),
