@@ -362,7 +362,10 @@ def write_leg_record(path, rec):
 # ---------------------------------------------------------------------------------------------------------------------
 def mode_record(steps, dt_, st_, res_, **extra):
     rec = {"value": steps / dt_, "ms_per_step": dt_ / steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3, "exchange_us": st_["t_exchange"] * 1e6,
-           "gemv_plus_comm_ms": (st_["t_gemv"] + st_["t_exchange"]) * 1e3, "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
+           "gemv_plus_comm_ms": (st_["t_gemv"] + st_["t_exchange"]) * 1e3,
+           # what is left of the iteration: the vector step, launch gaps, and whatever of the exchange is NOT on this stream's critical path
+           "other_us": (dt_ / steps - st_["t_gemv"] - st_["t_exchange"]) * 1e6,
+           "rel_residual_true": res_, "rel_residual_recursive": st_["rel_err"]}
     if "t_exchange_min" in st_:
         rec["exchange_us_min_over_ranks"] = st_["t_exchange_min"] * 1e6
     rec.update(extra)
