@@ -51,6 +51,12 @@ int run_positional_driver(int argc, char **argv, Solver &cg, const char *label)
     const auto &st = cg.stats();
     printf("GEMV %.6f ms/iter (%.1f GB/s), iteration %.6f ms\n", st.t_gemv * 1e3,
            st.t_gemv > 0 ? st.gemv_bytes / st.t_gemv / 1e9 : 0.0, st.t_iter * 1e3);
+    if (const char *sym = getenv("LAM_HIP_SYMMETRIC")) {
+        // the drivers have no flag for the symmetric product: when the environment asks for it, say whether the solve ran on it
+        int64_t eff = 0;
+        if (*sym && *sym != '0' && lam_hip_get_option(cg.context(), "symmetric_effective", &eff) == 0)
+            printf("Option symmetric (LAM_HIP_SYMMETRIC=%s): %s\n", sym, eff ? "effective" : "NOT effective (general GEMV)");
+    }
     printf("Done\n\n");
 
     printf("Writing solution to file ...\n");

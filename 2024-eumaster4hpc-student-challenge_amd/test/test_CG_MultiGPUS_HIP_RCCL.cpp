@@ -234,6 +234,13 @@ int run_solver(Solver &cg, const lam_bootstrap::Launch &L, const Options &o, int
                st.converged ? "Converged" : "Did not converge", st.num_iters, st.rel_err, t_cg, st.t_gemv * 1e3,
                st.t_gemv > 0 ? st.gemv_bytes / st.t_gemv / 1e9 : 0.0, st.t_exchange * 1e3);
     }
+    if (const char *sym = getenv("LAM_HIP_SYMMETRIC")) {
+        // no flag for the symmetric product here either: when the environment asks for it, say (on stderr: stdout is the CSV line)
+        // whether the solve ran on it
+        int64_t eff = 0;
+        if (root && *sym && *sym != '0' && lam_hip_get_option(cg.context(), "symmetric_effective", &eff) == 0)
+            fprintf(stderr, "Option symmetric (LAM_HIP_SYMMETRIC=%s): %s\n", sym, eff ? "effective" : "NOT effective (general GEMV)");
+    }
     if (!cg.save_result_to_file(sol_file)) {
         if (root) fprintf(stderr, "Failed to save solution\n");
         return 6;

@@ -83,6 +83,8 @@ def test_positional_drivers(golden, oracle, tmp_path, exe, env):
                   str(sol), str(g["max_iters"]), repr(g["tol"])], env=env)
         assert r.returncode == 0, r.stderr
         assert "Finished successfully" in r.stdout
+        if "LAM_HIP_SYMMETRIC" in env:          # the option must be APPLIED, not only requested
+            assert "Option symmetric (LAM_HIP_SYMMETRIC=2): effective" in r.stdout and "refused" not in r.stderr, r.stdout[-600:] + r.stderr[-600:]
         x = oracle.read_bin(str(sol)).reshape(-1)
         x_ref = oracle.read_bin(os.path.join(GOLDEN, g["tag"] + ".sol.bin")).reshape(-1)
         if g["converged"]:
@@ -536,6 +538,8 @@ def test_reference_file_grid_sizes(tmp_path, symmetric):
         f = x["csv"].split(",")
         assert x["match"] and len(f) == 10 and f[0] == str(x["n"]) and f[1] == "1" and float(f[8]) < 1e-9 and float(f[5]) > 0
         assert 0.97 * 358 <= x["iters"] <= 1.03 * 360, x
+        if symmetric:                            # applied, not only requested (the driver says so on stderr)
+            assert x.get("symmetric") == "effective", x
 
 def test_reference_scaling_grids_at_reduced_size(tmp_path, mock_async):
     """tools/sweep.py --grid scaling: the reference's strong-scaling (N = 20000 / 40000 / 50000 at P = 1, 2, 3, 4, 6, 8 --

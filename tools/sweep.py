@@ -120,6 +120,8 @@ def file_grid(exe, sol, out, files_dir, files_max_n, sizes):
         rc, line, err, wall = run_point(exe, args)
         f = line.split(",")
         rec = {"grid": "file", "n": n, "mode": mode, "csv": line, "wall_s": round(wall, 2)}
+        if "Option symmetric" in err:            # LAM_HIP_SYMMETRIC in the environment: the driver says whether the solve ran on it
+            rec["symmetric"] = "effective" if ": effective" in err else "NOT effective"
         if rc != 0 or len(f) != 10:
             rec["match"] = False
             rec["error"] = f"rc {rc}: {err.strip()[-300:]}"
