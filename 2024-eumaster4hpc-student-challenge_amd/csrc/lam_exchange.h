@@ -627,12 +627,13 @@ int setup_direct(lam_hip_ctx *c)
     return 0;
 }
 
-// Is the GEMV of iteration k timed (HIP-event pair on the launch stream, shard 0 only)?  Option "gemv_timing" = T
-// times every T-th iteration; each record is a marker packet between the iteration's kernels, so T > 1 keeps most
-// iterations free of them.
+// Is the GEMV of iteration k timed (HIP-event pair on the launch stream of EVERY local shard: lam_hip_stats.t_gemv is the slowest
+// shard's average -- on a real multi-GPU node that is the device that bounds the iteration)?  Option "gemv_timing" = T times every
+// T-th iteration; each record is a marker packet between the iteration's kernels, so T > 1 keeps most iterations free of them.
 bool timed_iteration(const lam_hip_ctx *c, const ShardBase &s, int k)
 {
-    return &s == &c->sh[0] && c->opt_gemv_timing > 0 && (k - 1) % c->opt_gemv_timing == 0;
+    (void)s;
+    return c->opt_gemv_timing > 0 && (k - 1) % c->opt_gemv_timing == 0;
 }
 
 // Can a launch of `blocks` workgroups of update_fused_kernel be resident all at once?  Its workgroups wait for each

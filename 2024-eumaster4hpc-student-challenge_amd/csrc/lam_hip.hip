@@ -584,8 +584,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     } cpu_account{c, cpu0};
     ShardBase &s0 = c->sh[0];
     c->prog_t = 0.0;               // the estimate of the iteration time carries over, the reference point does not
-    double gemv_ms = 0.0, xch_ms = 0.0;
-    int gemv_samples = 0;
+    IterTimes times;
     int enq = 0;
     // already converged in an earlier call?
     LAMCHK(set_dev(c, s0));
@@ -593,7 +592,8 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
     HIPCHK(c, hipStreamSynchronize(s0.stream));
     const bool stopped = s0.sc_host->stop != 0;
     const int k_first = c->k_done + 1;
-    for (int i = 0; i < kLag; i++) { s0.timed_slot[i] = false; s0.nx[i] = 0; }
+    for (auto &sh_ : c->sh)
+        for (int i = 0; i < kLag; i++) { sh_.timed_slot[i] = false; sh_.nx[i] = 0; }
     if (stopped) {
         // nothing to enqueue
     }
@@ -619,7 +619,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
             enq += cnt;
         }
     } else if (!c->rank_mode && c->total_shards > 1 && c->opt_host_threads != 0 && !c->cg_direct && !c->cg_exchange1) {
-        LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &gemv_ms, &gemv_samples, &xch_ms));
+        LAMCHK(iterate_threaded(c, iters, k_first, rel_error, &enq, &times));
         c->gather_pending = false;
     }
 #endif
@@ -632,7 +632,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
                 const int d = lag_check(c, s0, k);
                 if (d < 0) return d;
                 if (d != 0) break;
-                harvest_gemv_time(s0, slot, &gemv_ms, &gemv_samples, &xch_ms);
+                harvest_times(c, slot, &times);
             }
             const double te = now_s();
             LAMCHK(enqueue_iteration(c, k, rel_error, slot));
@@ -669,7 +669,7 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         LAMCHK(lam_hip_all_ok(c, 1, &all));
     }
     // harvest the GEMV timings still in the ring
-    for (int j = 0; j < kLag; j++) harvest_gemv_time(s0, j, &gemv_ms, &gemv_samples, &xch_ms);
+    for (int j = 0; j < kLag; j++) harvest_times(c, j, &times);
     LAMCHK(set_dev(c, s0));
     HIPCHK(c, hipMemcpyAsync(s0.sc_host, s0.sc, sizeof(CgScalars), hipMemcpyDeviceToHost, s0.stream));
     HIPCHK(c, hipStreamSynchronize(s0.stream));
@@ -685,8 +685,19 @@ int lam_hip_cg_iterate(lam_hip_ctx *c, int iters, double rel_error, lam_hip_stat
         st->rel_err = std::sqrt(sc.rr[sc.iters & 1] / sc.bb);
         st->t_total = t1 - t0;
         st->t_iter = ran > 0 ? (t1 - t0) / ran : 0.0;
-        st->t_gemv = gemv_samples > 0 ? gemv_ms * 1e-3 / gemv_samples : 0.0;
-        st->t_exchange = gemv_samples > 0 ? xch_ms * 1e-3 / gemv_samples : 0.0;
+        // the slowest local shard's average (one process driving several GPUs: the device that bounds the iteration); the fastest
+        // one's is kept next to it (options "gemv_ns_min_shard" / "gemv_ns_max_shard": their difference is the shards' skew)
+        double tmin = 0.0, tmax = 0.0;
+        for (size_t j = 0; j < c->sh.size(); j++) {
+            if (times.samples[j] == 0) continue;
+            const double avg = times.gemv_ms[j] * 1e-3 / times.samples[j];
+            tmax = std::max(tmax, avg);
+            tmin = tmin == 0.0 ? avg : std::min(tmin, avg);
+        }
+        c->t_gemv_min = tmin;
+        c->t_gemv_max = tmax;
+        st->t_gemv = tmax;
+        st->t_exchange = times.samples[0] > 0 ? times.xch_ms * 1e-3 / times.samples[0] : 0.0;
 #ifdef LAM_TUNING_VARIANTS
         if (c->persist_active && c->persist_ticks != nullptr) {
             // the persistent launch times its GEMV phases itself (constant-rate 100 MHz counter, reducer workgroup):
@@ -1136,6 +1147,8 @@ int lam_hip_get_option(const lam_hip_ctx *c, const char *name, int64_t *value)
         *value = count;
     }
     else if (!strcmp(name, "ranks_on_device")) *value = c->ranks_on_device;
+    else if (!strcmp(name, "gemv_ns_min_shard")) *value = (int64_t)(c->t_gemv_min * 1e9);
+    else if (!strcmp(name, "gemv_ns_max_shard")) *value = (int64_t)(c->t_gemv_max * 1e9);
     else if (!strcmp(name, "tuning_variants")) *value = Impl<double, double>::variant_available(1) ? 1 : 0;
     else if (!strcmp(name, "fuse_effective")) *value = c->fuse_active ? 1 : 0;
     else if (!strcmp(name, "persistent")) *value = c->opt_persistent;

@@ -401,33 +401,48 @@ struct HostBarrier {
 #endif
 
 
-// GEMV device time of the iteration that used ring slot `slot` (shard 0), if that iteration was timed, and the time of its exchange
-// steps (xt_begin / xt_end pairs)
-static void harvest_gemv_time(ShardBase &s0, int slot, double *ms_sum, int *samples, double *xch_ms_sum)
+// GEMV device time of the iteration that used ring slot `slot`, per local shard, if that iteration was timed; for shard 0 also the
+// time of its exchange steps (xt_begin / xt_end pairs)
+struct IterTimes {
+    double gemv_ms[kMaxShards] = {};
+    int samples[kMaxShards] = {};
+    double xch_ms = 0.0;
+};
+static void harvest_shard(ShardBase &s, int j, int slot, IterTimes *t)
 {
-    if (!s0.timed_slot[slot]) return;
-    s0.timed_slot[slot] = false;
-    const int nx = s0.nx[slot];
-    s0.nx[slot] = 0;
+    if (!s.timed_slot[slot]) return;
+    s.timed_slot[slot] = false;
+    const int nx = j == 0 ? s.nx[slot] : 0;
+    if (j == 0) s.nx[slot] = 0;
     float ms = 0.f, ms2 = 0.f;
-    if (hipEventElapsedTime(&ms, s0.ev_g0[slot], s0.ev_g1[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (s0.split_slot[slot] && hipEventElapsedTime(&ms2, s0.ev_g2[slot], s0.ev_g3[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventElapsedTime(&ms, s.ev_g0[slot], s.ev_g1[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (s.split_slot[slot] && hipEventElapsedTime(&ms2, s.ev_g2[slot], s.ev_g3[slot]) != hipSuccess) { (void)hipGetLastError(); return; }
     double xms = 0.0;
-    for (int j = 0; j < nx; j++) {
+    for (int q = 0; q < nx; q++) {
         float x = 0.f;
-        hipError_t e = hipEventElapsedTime(&x, s0.ev_x[slot][2 * j], s0.ev_x[slot][2 * j + 1]);
+        hipError_t e = hipEventElapsedTime(&x, s.ev_x[slot][2 * q], s.ev_x[slot][2 * q + 1]);
         if (e == hipErrorNotReady) {
             // the all-gather of p runs on the comm stream and may still be in flight when its iteration has reported (a few
             // microseconds: the next GEMV's second panel waits for it)
             (void)hipGetLastError();
-            if (hipEventSynchronize(s0.ev_x[slot][2 * j + 1]) == hipSuccess) e = hipEventElapsedTime(&x, s0.ev_x[slot][2 * j], s0.ev_x[slot][2 * j + 1]);
+            if (hipEventSynchronize(s.ev_x[slot][2 * q + 1]) == hipSuccess) e = hipEventElapsedTime(&x, s.ev_x[slot][2 * q], s.ev_x[slot][2 * q + 1]);
         }
         if (e != hipSuccess) { (void)hipGetLastError(); return; }
         xms += x;
     }
-    *ms_sum += ms + ms2;
-    *xch_ms_sum += xms;
-    (*samples)++;
+    t->gemv_ms[j] += ms + ms2;
+    t->samples[j]++;
+    if (j == 0) t->xch_ms += xms;
+}
+// all local shards (the caller's current device is restored to shard 0's)
+static void harvest_times(lam_hip_ctx *c, int slot, IterTimes *t)
+{
+    for (size_t j = 0; j < c->sh.size(); j++) {
+        if (!c->sh[j].timed_slot[slot]) continue;
+        if (c->sh.size() > 1 && set_dev(c, c->sh[j]) != 0) continue;
+        harvest_shard(c->sh[j], (int)j, slot, t);
+    }
+    if (c->sh.size() > 1) (void)set_dev(c, c->sh[0]);
 }
 
 // The lag rule (every enqueue loop uses it).  Before enqueueing iteration k the host makes sure iteration k - kLag
@@ -457,7 +472,7 @@ static int lag_check(lam_hip_ctx *c, ShardBase &s0, int k)
 // from its own OpenMP thread, ConjugateGradient_MultiGPUS_CUDA.cu:264-283,337-378).  With one thread for P shards an
 // iteration costs the host 3P launches + ~3P event records + 3P(P-1) stream waits one after the other; here they are
 // issued P-wide, with a host barrier between the phases (a stream wait must follow the record it refers to).
-static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_error, int *enq_out, double *gemv_ms, int *gemv_samples, double *xch_ms)
+static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_error, int *enq_out, IterTimes *times)
 {
     const int L = (int)c->sh.size();
     HostBarrier bar(L);
@@ -481,7 +496,7 @@ static int iterate_threaded(lam_hip_ctx *c, int iters, int k_first, double rel_e
                     const int d = lag_check(c, s, k);
                     if (d < 0) { rc = d; flags |= 1; }
                     else if (d != 0) flags |= 2;
-                    else harvest_gemv_time(s, slot, gemv_ms, gemv_samples, xch_ms);
+                    else harvest_shard(s, 0, slot, times);
                 }
                 if (bar.wait(flags) != 0) break;
             }

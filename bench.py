@@ -576,6 +576,8 @@ def one_process_measure(lam, args, n_gpus, part, leg_name=None):
             st, dt = run_config(s, n, args.warmup, args.steps, nobarrier, ramp_s=args.ramp if leg_name is None else min(args.ramp, 0.3))
             rec["kernel"] = s.gemv_kernel_name()
             rec["cold_start"] = run_config.cold
+            gemv_fastest = s.get_option("gemv_ns_min_shard") * 1e-6      # ms; st["t_gemv"] is the slowest shard's: the skew between them
+            rec["gemv_ms_fastest_shard"] = gemv_fastest
             effective = s.get_option("exchange_effective")
             rec["exchange_effective"] = effective
             host_us = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
@@ -592,7 +594,8 @@ def one_process_measure(lam, args, n_gpus, part, leg_name=None):
                 return abs(err_ / ref_err - 1) if ref_err else None
 
             modes = {"default": eff_label,
-                     eff_label: mode_record(args.steps, dt, st, true_res, host_enqueue_us_per_step=host_us, vs_one_gpu=vs_ref(st["rel_err"]))}
+                     eff_label: mode_record(args.steps, dt, st, true_res, host_enqueue_us_per_step=host_us, vs_one_gpu=vs_ref(st["rel_err"]),
+                                            gemv_ms_fastest_shard=gemv_fastest)}
             rec["exchange_modes"] = modes
             timed_local = make_timed_local(s, args, modes, vs_ref)
             timed_local(LOCAL_LABELS[1] + ", join through shard 0", exchange=1, exchange_join=1)
@@ -659,7 +662,8 @@ def make_timed_local(s, args, modes, vs_ref, leg_name=None):
             dt_ = time.perf_counter() - t0_
             h1_ = s.get_option("host_enqueue_ns")
             res_ = s.true_residual()
-            rec = mode_record(args.steps, dt_, st_, res_, host_enqueue_us_per_step=(h1_ - h0_) / args.steps * 1e-3, vs_one_gpu=vs_ref(st_["rel_err"]))
+            rec = mode_record(args.steps, dt_, st_, res_, host_enqueue_us_per_step=(h1_ - h0_) / args.steps * 1e-3, vs_one_gpu=vs_ref(st_["rel_err"]),
+                              gemv_ms_fastest_shard=s.get_option("gemv_ns_min_shard") * 1e-6)       # gemv_ms is the SLOWEST shard's
             if experimental:
                 rec["experimental"] = True
             if not (abs(res_ / st_["rel_err"] - 1) < 1e-6 and (rec["vs_one_gpu"] is None or rec["vs_one_gpu"] < tol_vs)):

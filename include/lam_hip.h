@@ -68,7 +68,7 @@ typedef struct lam_hip_stats {
     int32_t num_iters;    /* loop counter on exit: converging iteration, or max_iters+1 at the cap */
     int32_t converged;    /* solve()'s bool */
     double rel_err;       /* sqrt(rr/bb), the recursive relative residual */
-    double t_gemv;        /* average seconds per iteration in the GEMV kernel (device time) */
+    double t_gemv;        /* average seconds per iteration in the GEMV kernel (device time; several local shards: the slowest one's) */
     double t_iter;        /* average seconds per iteration (wall, whole loop / iterations run) */
     double t_total;       /* wall seconds of the call */
     double t_comm_init;   /* seconds spent creating the RCCL communicator (0 if none) */
@@ -280,7 +280,8 @@ int lam_hip_gemv_kernel_name(const lam_hip_ctx *ctx, char *buf, size_t len);
  *   "reuse_matrix"  1 (default) = lam_hip_set_problem keeps the matrix allocation when it is large enough (grow-only).
  *   "upload_staging" 1 = lam_hip_upload_rows copies through two pinned staging buffers (default 0: measured slower).
  *   get only: "row_pitch" (elements between rows on the device), "collectives_enqueued", "rccl_ranks" (ncclCommCount of
- *                   the context's communicator, 0 without one), "ranks_on_device", "host_cpu_ns", "host_enqueue_ns",
+ *                   the context's communicator, 0 without one), "ranks_on_device", "gemv_ns_min_shard" / "gemv_ns_max_shard" (fastest /
+ *                   slowest local shard's average GEMV of the last cg_iterate call: their difference is the skew), "host_cpu_ns", "host_enqueue_ns",
  *                   "hip_calls_launch" / "_record" / "_wait" / "_setdevice", "tuning_variants" (1 in the tuning build). */
 int lam_hip_set_option(lam_hip_ctx *ctx, const char *name, int64_t value);
 int lam_hip_get_option(const lam_hip_ctx *ctx, const char *name, int64_t *value);

@@ -1116,6 +1116,9 @@ def test_exchange_time_is_sampled_with_the_gemv(lam, shards, n, exchange):
             st = s.cg_iterate(50, 0.0)
             assert s.get_option("exchange_effective") == exchange
             assert (st["t_gemv"] > 0) == (timing != 0) and (st["t_exchange"] > 0) == (timing != 0), st
+            # t_gemv is the SLOWEST local shard's average GEMV (every shard is timed); the fastest one's is kept beside it
+            lo, hi = s.get_option("gemv_ns_min_shard"), s.get_option("gemv_ns_max_shard")
+            assert (0 < lo <= hi and abs(hi * 1e-9 - st["t_gemv"]) < 2e-9) if timing else (lo == hi == 0), (lo, hi, st)
             assert st["t_exchange"] < 0.05 and st["num_iters"] == 51, st     # a join on one device: microseconds, not a stall
             res.append((st["rel_err"], s.solution().tobytes()))
     assert res[0] == res[1] == res[2]
@@ -1256,7 +1259,7 @@ def test_one_process_direct_exchange_matches_events(shards, n):
     assert out["direct_nosplit"]["x"] and out["direct_nosplit"]["iters"] == out["events"]["iters"], out
     assert out["events"]["per_iter"]["wait"] >= 3 * shards * (shards - 1) - 1e-9
     for k in ("direct", "direct_nosplit"):
-        assert out[k]["per_iter"]["wait"] == 0 and out[k]["per_iter"]["record"] <= 0.6, out[k]      # only the sampled GEMV timing pair
+        assert out[k]["per_iter"]["wait"] == 0 and out[k]["per_iter"]["record"] <= 0.6 * shards, out[k]      # only the sampled GEMV timing pairs (one per shard)
     assert abs(out["direct_nosplit"]["per_iter"]["launch"] - 2 * shards) < 0.01                    # GEMV + fused update per shard
     # not requested: shards sharing a device stay on the event exchange
     env.pop("LAM_HIP_DIRECT_SAME_DEVICE")
