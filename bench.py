@@ -346,6 +346,7 @@ def run_leg(args, leg, nprocs, timeout, rank_env=None, rdzv_file=None, expect_re
                     p.wait(timeout=10)
                 except Exception:   # noqa: BLE001
                     pass
+            p.errf.close()
         import shutil
         shutil.rmtree(work, ignore_errors=True)
 
