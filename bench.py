@@ -697,6 +697,17 @@ def leg_main(args):
         ctypes.CDLL(None).prctl(1, signal.SIGKILL)          # PR_SET_PDEATHSIG
     except Exception:   # noqa: BLE001
         pass
+    if args.leg.startswith("_selftest"):
+        # no GPU, no library: what tests/test_bench_cpu.py drives run_leg with (a record, a failure, a hang, one bad rank of several)
+        rank = int(os.environ.get("RANK", "0"))
+        if args.leg == "_selftest_hang":
+            time.sleep(600)
+        if args.leg == "_selftest_fail" or (args.leg == "_selftest_rank1_fails" and rank == 1):
+            sys.stderr.write(f"selftest: rank {rank} fails on purpose\n")
+            sys.exit(7)
+        if rank == 0:
+            write_leg_record(args.leg_out, {"value": 1.0, "world": int(os.environ.get("WORLD_SIZE", "1")), "rdzv_file": os.environ.get("LAM_RDZV_FILE")})
+        return 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
