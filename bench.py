@@ -690,6 +690,22 @@ def public(rec):
     return out
 
 
+def merge_direct(target_modes, leg_rec, target_res):
+    """Merge an EXPERIMENTAL leg's exchange modes into the modes of the topology it belongs to, checked against that topology's
+    residual (all exchanges are deterministic and agree to rounding); a leg without a record becomes one error entry."""
+    if target_modes is None or leg_rec is None:
+        return
+    got = leg_rec.get("exchange_modes") or {}
+    for label, m in got.items():
+        if isinstance(m, dict) and "rel_residual_true" in m and target_res and not abs(m["rel_residual_true"] / target_res - 1) < 1e-6 and "error" not in m:
+            m["error"] = "residual differs from the default exchange: WRONG RESULT on this hardware"
+        target_modes[label] = m
+    if not got:
+        target_modes["direct (experimental leg)"] = {"error": leg_rec.get("error", "the leg produced no record"), "experimental": True}
+    elif leg_rec.get("error"):
+        target_modes["direct (experimental leg)"] = {"error": leg_rec["error"], "experimental": True}
+
+
 def leg_main(args):
     """Child-process mode: run one leg and leave its record in --leg-out (rank 0 of the leg writes it)."""
     try:        # a leg lives in a session of its own (so that its parent can kill all of it): make sure it also DIES with its parent
@@ -880,20 +896,7 @@ def main():
         true_res = s.true_residual()
         check, failures = self_check(lam, args, 1, st, true_res, 0, None, symmetric=args.symmetric)
 
-    # merge the experimental legs into the exchange modes of the topology they belong to, checked against that topology's residual
-    def merge_direct(target_modes, leg_rec, target_res):
-        if target_modes is None or leg_rec is None:
-            return
-        got = leg_rec.get("exchange_modes") or {}
-        for label, m in got.items():
-            if isinstance(m, dict) and "rel_residual_true" in m and target_res and not abs(m["rel_residual_true"] / target_res - 1) < 1e-6 and "error" not in m:
-                m["error"] = "residual differs from the default exchange: WRONG RESULT on this hardware"
-            target_modes[label] = m
-        if not got:
-            target_modes["direct (experimental leg)"] = {"error": leg_rec.get("error", "the leg produced no record"), "experimental": True}
-        elif leg_rec.get("error"):
-            target_modes["direct (experimental leg)"] = {"error": leg_rec["error"], "experimental": True}
-
+    # (the experimental legs are merged into the exchange modes of the topology they belong to: merge_direct)
     other_topology = None
     if rank == 0 and (n_gpus > 1 or forced_rccl):
         if use_dist:

@@ -60,3 +60,16 @@ def test_records_and_the_merge_of_an_experimental_leg():
     assert pub["value"] == 200.0 and "st" not in pub and "dt" not in pub and pub["self_check"]["passed"]
     bad = bench.public(dict(rec, failures=["residual differs"]))
     assert bad["value"] is None and bad["value_unchecked"] == 200.0 and "residual differs" in bad["error"]
+
+
+def test_merge_of_an_experimental_leg_into_its_topology():
+    modes = {"default": "a", "a": {"value": 100.0, "rel_residual_true": 0.5}}
+    bench.merge_direct(modes, {"exchange_modes": {"direct": {"value": 110.0, "rel_residual_true": 0.5 * (1 + 1e-9)}}}, 0.5)
+    assert modes["direct"]["value"] == 110.0 and "error" not in modes["direct"]
+    bench.merge_direct(modes, {"exchange_modes": {"direct2": {"value": 120.0, "rel_residual_true": 0.7}}}, 0.5)
+    assert "WRONG RESULT" in modes["direct2"]["error"]                       # another residual than the default exchange's
+    bench.merge_direct(modes, {"error": "process 0 exited with signal 9", "leg_wall_s": 1.0}, 0.5)
+    assert modes["direct (experimental leg)"] == {"error": "process 0 exited with signal 9", "experimental": True}
+    assert modes["a"]["value"] == 100.0                                      # the headline's record is untouched
+    bench.merge_direct(None, {"error": "x"}, 0.5)                            # no modes (one GPU) / no leg: nothing to do
+    bench.merge_direct(modes, None, 0.5)
