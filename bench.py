@@ -264,6 +264,81 @@ def traffic_record(n, n_gpus):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# clocks / power during the measurement ("clocks/power state noted")
+# ---------------------------------------------------------------------------------------------------------------------
+_SAMPLER = r"""
+import ctypes, json, subprocess, sys, time
+ctypes.CDLL(None).prctl(1, 9)      # PR_SET_PDEATHSIG: die with the bench process
+out = open(sys.argv[1], "a")
+while True:
+    t = time.time()
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out.write(json.dumps({"t": t, "smi": json.loads(line)}) + "\n")
+        out.flush()
+    except Exception:
+        pass
+    time.sleep(0.2)
+"""
+
+
+class DeviceStateSampler:
+    """A child process (started BEFORE this process touches the GPU; it only reads sysfs through rocm-smi) that notes the device's
+    clocks and power every ~0.3 s; summary() reports what it saw inside a time window -- the headline's settle + warm-up + timed
+    steps.  Best effort: no rocm-smi, no record."""
+
+    def __init__(self):
+        import shutil
+        self.proc, self.path = None, None
+        if shutil.which("rocm-smi") is None:
+            return
+        fd, self.path = tempfile.mkstemp(prefix="lam_smi_", suffix=".jsonl")
+        os.close(fd)
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", _SAMPLER, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        except Exception:   # noqa: BLE001
+            self.proc = None
+
+    def stop(self):
+        if self.proc is not None and self.proc.poll() is None:
+            try:
+                os.killpg(self.proc.pid, signal.SIGKILL)
+                self.proc.wait(timeout=5)
+            except Exception:   # noqa: BLE001
+                pass
+        self.proc = None
+
+    def summary(self, t0, t1):
+        self.stop()
+        if self.path is None:
+            return None
+        try:
+            rows = [json.loads(l) for l in open(self.path) if l.strip()]
+            os.unlink(self.path)
+        except Exception:   # noqa: BLE001
+            return None
+        inside = [r for r in rows if t0 <= r["t"] <= t1] or rows[-1:]
+
+        def stat(key, unit):
+            vals = []
+            for r in inside:
+                for card in r["smi"].values():
+                    v = str(card.get(key, "")).strip("()").lower().replace(unit, "")
+                    try:
+                        vals.append(float(v))
+                    except ValueError:
+                        pass
+            vals.sort()
+            return {"min": vals[0], "median": vals[len(vals) // 2], "max": vals[-1]} if vals else None
+
+        return {"samples_in_window": len([r for r in rows if t0 <= r["t"] <= t1]), "window_s": t1 - t0,
+                "sclk_mhz": stat("sclk clock speed:", "mhz"), "mclk_mhz": stat("mclk clock speed:", "mhz"), "fclk_mhz": stat("fclk clock speed:", "mhz"),
+                "socket_power_w": stat("Current Socket Graphics Package Power (W)", "w"),
+                "how": "rocm-smi --showclocks --showpower sampled every ~0.3 s by a child process during the headline's settling launches, warm-up and timed steps"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # legs: measurements that run in child processes of their own
 # ---------------------------------------------------------------------------------------------------------------------
 def maybe_die(leg, where):
@@ -826,6 +901,9 @@ def main():
         if live_traffic[0] is None:
             sys.stderr.write(f"[bench] live PMC traffic measurement not available: {live_traffic[1]}\n")
 
+    sampler = DeviceStateSampler() if solo and not profiled and os.environ.get("LAM_BENCH_NO_SAMPLER", "0") in ("", "0") else None
+    t_window0 = time.time()
+
     # N > 1: the legs (see the module docstring).  `other` = the topology this process is NOT; `direct_*` = the EXPERIMENTAL
     # exchange of either topology, each in processes of its own.
     legs = {}
@@ -861,7 +939,7 @@ def main():
         rdzv.barrier()
 
     # ---- this process's own topology ------------------------------------------------------------------------------------
-    exchange_modes, effective_exchange, rccl_info, shard_devices = None, None, None, None
+    exchange_modes, effective_exchange, rccl_info, shard_devices, device_state = None, None, None, None, None
     if use_dist:
         rec = rank_mode_measure(lam, args, rdzv, "main")
         st, dt, true_res, check, failures = rec["st"], rec["dt"], rec["true_res"], rec["self_check"], rec["failures"]
@@ -893,6 +971,7 @@ def main():
         parallelism = "1 GPU"
         # host time the library spent issuing one iteration of the headline configuration (its waits for the device excluded)
         host_us_per_step = (s.get_option("host_enqueue_ns") - host_ns0) * 1e-3 / ((args.warmup + args.steps) * (2 if args.ramp > 0 else 1))
+        device_state = sampler.summary(t_window0, time.time()) if sampler is not None else None
         true_res = s.true_residual()
         check, failures = self_check(lam, args, 1, st, true_res, 0, None, symmetric=args.symmetric)
 
@@ -1049,6 +1128,7 @@ def main():
                           "rccl_ranks": rccl_info["rccl_ranks"] if rccl_info else None,
                           "rccl_calls_enqueued_rank0": rccl_info["rccl_calls_enqueued_rank0"] if rccl_info else None,
                           "profiler_detected": profiled},
+        **({"device_state": device_state} if device_state else {}),
     }
     if n_gpus > 1 and rank == 0:
         # the topology this process is not, measured by child processes in front of the headline (None: legs were switched off)
