@@ -90,6 +90,20 @@ def test_dot_axpby_match_oracle(lam, oracle, n):
     np.testing.assert_allclose(z, z_ref, rtol=4e-16, atol=0)   # FMA contraction: <= 1 ulp
 
 
+@pytest.mark.parametrize("n", [1, 255, 65536, 1 << 20])
+def test_dot_axpby_are_exact_on_integer_data(lam, n):
+    """dot (ConjugateGradient_CPU_MPI_OMP.hpp:446-467) and axpby (:469-480) on small integers: every product and partial sum is an
+    exactly representable integer, so the two-stage GPU reduction must return the closed forms BIT FOR BIT whatever its order:
+    sum i = n (n + 1) / 2, sum i^2 = n (n + 1) (2 n + 1) / 6 (n <= 65536: below 2^53), 2 x - 3 y elementwise."""
+    x = np.arange(1, n + 1, dtype=np.float64)
+    with lam.Solver(lam.F64) as s:
+        assert s.dot(x, np.ones(n)) == n * (n + 1) // 2
+        if n <= 65536:
+            assert s.dot(x, x) == n * (n + 1) * (2 * n + 1) // 6
+        z = s.axpby(2.0, x, -3.0, x[::-1].copy())
+    assert np.array_equal(z, 2.0 * x - 3.0 * x[::-1])
+
+
 # ------------------------------------------------------------------------------------------------
 # CG: golden fixtures produced by the reference (file mode)
 # ------------------------------------------------------------------------------------------------
@@ -609,6 +623,32 @@ def test_config3_shape_eight_shards_full_size(lam):
     (e1, t1, x1), (e8, t8, x8) = res
     assert abs(e8 / e1 - 1) < 1e-9 and abs(t8 / e8 - 1) < 1e-6 and abs(t1 / e1 - 1) < 1e-6
     assert np.linalg.norm(x8 - x1) / np.linalg.norm(x1) < 1e-10
+
+
+@pytest.mark.parametrize("dtype_name,n,shards,symmetric", [("F64", 65536, 1, 0), ("F64", 65536, 8, 0), ("F64", 65536, 3, 0), ("F64", 65536, 1, 2),
+                                                          ("F32", 131072, 1, 0), ("F32", 131072, 1, 2), ("BF16", 65536, 2, 0), ("F64", 50000, 6, 0)])
+def test_full_size_gemv_is_exact_on_integer_data(lam, dtype_name, n, shards, symmetric):
+    """A known answer at the BASELINE sizes that needs no oracle and no tolerance: the generate-mode matrix tridiag(1, 2, 1)
+    (ConjugateGradient_CPU_MPI_OMP.hpp:237-247) times x = (1, 2, ..., N) is 4 i in every interior row, 4 in the first and 3 N - 1 in
+    the last -- small integers, so every product and every partial sum is exact in fp64, in fp32 (<= 3 * 131072 < 2^24) and with
+    bf16 storage (the entries 1 and 2 are bf16 numbers), whatever the summation order: the GEMV must return it BIT FOR BIT.  One
+    shard, the 8-way split of configs[2], uneven splits (65536 on 3, 50000 on 6 shards), the symmetric product; through
+    lam_hip_gemv (the C ABI).  A * 1 = (3, 4, ..., 4, 3) likewise."""
+    dt = getattr(lam, dtype_name)
+    vdt = np.float64 if dtype_name == "F64" else np.float32
+    with lam.Solver(dt, device_ids=[0] * shards) as s:
+        assert s.generate_matrix(n, n)
+        s.set_option("symmetric", symmetric)
+        x = np.arange(1, n + 1, dtype=vdt)
+        want = 4.0 * x
+        want[0], want[-1] = 4.0, 3.0 * n - 1.0
+        y = s.gemv(x)
+        assert y.dtype == vdt and np.array_equal(y, want.astype(vdt)), np.flatnonzero(y != want)[:5]
+        ones = s.gemv(np.ones(n, dtype=vdt))
+        want1 = np.full(n, 4.0, dtype=vdt)
+        want1[0] = want1[-1] = 3.0
+        assert np.array_equal(ones, want1)
+        assert s.get_option("symmetric_effective") == (1 if symmetric and shards == 1 else 0)
 
 
 @pytest.mark.parametrize("dtype_name", ["F32", "BF16"])
