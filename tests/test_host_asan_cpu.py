@@ -20,7 +20,7 @@ ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_err
 
 @pytest.fixture(scope="module")
 def host_asan():
-    r = subprocess.run(["make", "-C", HERE], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", HERE, "all"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return EXE
 
@@ -79,3 +79,28 @@ def test_launcher_glue_under_sanitizers(host_asan, tmp_path):
     want = "".join(f"{(0xA5 ^ (i * 7)) & 0xff:02x}" for i in range(128))          # the fake's lam_hip_get_unique_id
     assert f0[3] == f1[3] == want
     assert not os.path.exists(idf)                      # rank 0 removed the rendezvous file
+
+
+def test_heat_assembler_under_sanitizers(host_asan, tmp_path):
+    """apps/heat_system.cpp (BASELINE configs[4]: the 2-D heat problem as a dense SPD system, file format of the reference) is host
+    code that indexes an n x n matrix with n = (nx-2)(ny-2): the sanitized build must write byte for byte what the committed
+    12 x 12 fixture holds, handle a non-square grid, and refuse bad arguments without touching memory it does not own."""
+    from conftest import GOLDEN
+    exe = os.path.join(HERE, "heat_asan.out")
+    m, b = str(tmp_path / "m.bin"), str(tmp_path / "b.bin")
+    r = subprocess.run([exe, "assemble", "12", "12", m, b], capture_output=True, text=True, timeout=120, env=ENV)
+    _clean(r)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(m, "rb").read() == open(os.path.join(GOLDEN, "heat_12x12.matrix.bin"), "rb").read()
+    assert open(b, "rb").read() == open(os.path.join(GOLDEN, "heat_12x12.rhs.bin"), "rb").read()
+    r = subprocess.run([exe, "assemble", "7", "19", m, b], capture_output=True, text=True, timeout=120, env=ENV)
+    _clean(r)
+    assert r.returncode == 0 and os.path.getsize(m) == 16 + 8 * (5 * 17) ** 2 and os.path.getsize(b) == 16 + 8 * 5 * 17
+    # a solution vector back on the grid (the reference's output format), then the refusals
+    r = subprocess.run([exe, "field", "7", "19", b, str(tmp_path / "heat.bin")], capture_output=True, text=True, timeout=120, env=ENV)
+    _clean(r)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for bad in (["assemble", "2", "12", m, b], ["assemble", "12"], ["field", "7", "19", str(tmp_path / "missing.bin"), str(tmp_path / "h.bin")], ["nonsense"]):
+        r = subprocess.run([exe] + bad, capture_output=True, text=True, timeout=60, env=ENV)
+        _clean(r)
+        assert r.returncode != 0, bad
