@@ -173,7 +173,7 @@ struct lam_hip_ctx {
                                                 // in-kernel hand-overs (lam_kernels.h, MailSlot) cannot meet a stale equal; the same
                                                 // on every rank (all ranks enqueue the same iterations)
     int *direct_err = nullptr;                  // pinned host: a bounded in-kernel wait expired ([0] = which, see cg_iterate)
-    double *agree_buf = nullptr;                // 4 KiB device scratch of the small set-up collectives (kept: no hipFree in them)
+    double *agree_buf = nullptr;                // kAgreeBytes of device scratch of the small set-up collectives (kept: no hipFree in them)
     bool cg_exchange1 = false;     // the exchange the current CG state was initialised for
     double t_gemv_min = 0.0, t_gemv_max = 0.0;      // fastest / slowest local shard's average GEMV time of the last cg_iterate call (seconds)
     int xt_slot = -1;              // timing-ring slot of the iteration being enqueued if that iteration is timed (option gemv_timing),

@@ -184,8 +184,8 @@ int count_ranks_on_device(lam_hip_ctx *c)
     ShardBase &s = c->sh[0];
     LAMCHK(set_dev(c, s));
     constexpr size_t kRec = 128;
-    static_assert(kRec * kMaxShards <= 4096, "device records fit the set-up scratch");
-    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, 4096));
+    static_assert(kRec * kMaxShards <= kAgreeBytes, "device records fit the set-up scratch");
+    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, kAgreeBytes));
     std::vector<char> host(kRec * (size_t)c->nranks, 0);
     char *mine = host.data() + kRec * (size_t)c->rank;
     (void)gethostname(mine, 63);
@@ -577,8 +577,8 @@ int setup_direct(lam_hip_ctx *c)
     const int P = c->nranks;
     constexpr size_t kRec = 256;
     static_assert(sizeof(DirectHello) <= kRec, "hello record");
-    static_assert(kRec * kMaxShards <= 4096, "hello records fit the set-up scratch");
-    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, 4096));
+    static_assert(kRec * kMaxShards <= kAgreeBytes, "hello records fit the set-up scratch");
+    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, kAgreeBytes));
     struct { void *p; } dev{c->agree_buf};       // kept for the life of the context (no hipFree in a collective path)
     std::vector<char> host(kRec * (size_t)P, 0);
     DirectHello me;

@@ -75,6 +75,7 @@ int lam_hip_device_count(int *count)
 
 const char *lam_hip_last_error(const lam_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static_assert(lam::kMaxShards == LAM_HIP_MAX_SHARDS, "include/lam_hip.h states the limit");
 int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *device_ids)
 {
     if (!out) return LAM_HIP_EINVAL;
@@ -238,8 +239,10 @@ int lam_hip_set_problem(lam_hip_ctx *c, uint64_t n)
         void **vecs[] = {&s.Ap, &s.x, &s.r, &s.b};
         for (auto v : vecs) HIPCHK(c, hipMalloc(v, s.nrows * ev + 16));
         s.gemv_blocks = dispatch(c, [&](auto impl) -> int { return decltype(impl)::gemv_grid(c, s.nrows); });
-        // worst case over kernel variants (generic kernel: 4 rows per workgroup)
-        const int gemv_blocks_max = (int)s.nrows + 1;
+        // worst case over kernel variants (generic kernel: 4 rows per workgroup) and the symmetric product, whose second pass
+        // leaves one partial per kSymvReduceRows entries of the FULL-length vector whatever the shard's share of the rows (more
+        // than the shard has rows from 33 shards on)
+        const int gemv_blocks_max = (int)std::max<uint64_t>(s.nrows, (n + kSymvReduceRows - 1) / kSymvReduceRows) + 1;
         s.vec_blocks = vec_grid(s.nrows);
         HIPCHK(c, hipMalloc((void **)&s.part_gemv, sizeof(double) * (size_t)gemv_blocks_max));
         s.part_gemv_cap = gemv_blocks_max;
@@ -1040,7 +1043,7 @@ int lam_hip_all_ok(lam_hip_ctx *c, int local_ok, int *global_ok)
     LAMCHK(set_dev(c, s));
     // No hipMalloc/hipFree here: hipFree waits for the whole device, and when the ranks are threads of one
     // process (the test double) that includes peers' kernels that are waiting for THIS rank's next call.
-    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, 4096));
+    if (c->agree_buf == nullptr) HIPCHK(c, hipMalloc((void **)&c->agree_buf, kAgreeBytes));
     double v = local_ok ? 0.0 : 1.0;       // number of ranks that failed
     HIPCHK(c, hipMemcpyAsync(c->agree_buf, &v, sizeof v, hipMemcpyHostToDevice, s.stream));
     NCCLCHK(c, ncclAllReduce(c->agree_buf, c->agree_buf, 1, ncclDouble, ncclSum, c->comm, s.stream));

@@ -41,7 +41,8 @@ namespace lam {
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxShards = 16;
+constexpr int kMaxShards = 64;         // shards of one process / ranks of one communicator (the reference's largest published run: 64 GPUs)
+constexpr size_t kAgreeBytes = 256 * (size_t)kMaxShards;   // device scratch of the small set-up collectives: one 256-byte record per rank
 
 struct CgScalars {
     double bb;        // b.b

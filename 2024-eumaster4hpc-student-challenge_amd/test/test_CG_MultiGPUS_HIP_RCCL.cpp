@@ -143,8 +143,8 @@ static int real_main(int argc, char **argv, const lam_bootstrap::Launch &L)
         fprintf(stderr, "No GPU: %s\n", lam_hip_last_error(nullptr));
         return 1;
     }
-    if (o.shards != 0 && (o.shards < 1 || o.shards > 16 || L.size > 1 || !strcmp(precision, "bf16"))) {
-        if (root) fprintf(stderr, "Option -P takes 1 ... 16 shards, runs as ONE process (no multi-rank launcher) and in f64 / f32\n");
+    if (o.shards != 0 && (o.shards < 1 || o.shards > LAM_HIP_MAX_SHARDS || L.size > 1 || !strcmp(precision, "bf16"))) {
+        if (root) fprintf(stderr, "Option -P takes 1 ... %d shards, runs as ONE process (no multi-rank launcher) and in f64 / f32\n", LAM_HIP_MAX_SHARDS);
         return 1;
     }
     int rc;

@@ -46,6 +46,10 @@ extern "C" {
  *      exchange too (option "exchange" = 1; was 0). */
 #define LAM_HIP_ABI_VERSION 4
 
+/* most row shards of one process (lam_hip_create) / ranks of one communicator (lam_hip_create_rank); more -> LAM_HIP_EINVAL.
+ * 16 until round 5; the reference's largest published GPU run has 64 ranks (TESTS/results/STRESS_TEST_GPU_MPI.txt:18). */
+#define LAM_HIP_MAX_SHARDS 64
+
 /* storage / arithmetic type of the matrix and vectors */
 #define LAM_HIP_F64 0  /* double everywhere (the reference drivers hard-code <double>) */
 #define LAM_HIP_F32 1  /* float storage, float FMA, double only for the reduced scalars */

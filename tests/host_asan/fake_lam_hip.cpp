@@ -33,7 +33,7 @@ int lam_hip_device_count(int *count) { *count = 1; return 0; }
 const char *lam_hip_last_error(const lam_hip_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
 int lam_hip_create(lam_hip_ctx **out, int dtype, int n_shards, const int *)
 {
-    if (n_shards < 1 || n_shards > 16) return fail(nullptr, LAM_HIP_EINVAL, "n_shards");
+    if (n_shards < 1 || n_shards > LAM_HIP_MAX_SHARDS) return fail(nullptr, LAM_HIP_EINVAL, "n_shards");
     auto *c = new lam_hip_ctx;
     c->dtype = dtype; c->total = c->local = n_shards;
     *out = c;
@@ -46,7 +46,7 @@ int lam_hip_get_unique_id(void *id)
 }
 int lam_hip_create_rank(lam_hip_ctx **out, int dtype, int, int rank, int nranks, const void *)
 {
-    if (nranks < 1 || nranks > 16 || rank < 0 || rank >= nranks) return fail(nullptr, LAM_HIP_EINVAL, "rank");
+    if (nranks < 1 || nranks > LAM_HIP_MAX_SHARDS || rank < 0 || rank >= nranks) return fail(nullptr, LAM_HIP_EINVAL, "rank");
     auto *c = new lam_hip_ctx;
     c->dtype = dtype; c->total = nranks; c->local = 1; c->rank = rank;
     *out = c;

@@ -42,7 +42,7 @@ static int run_plan()
 {
     // the partition rule (ConjugateGradient_CPU_MPI_OMP.hpp:176-184): contiguous, complete, remainder on the last shard
     for (uint64_t n : {1ull, 2ull, 7ull, 100ull, 1001ull, 65536ull, 50000ull, 4294967311ull})
-        for (int P = 1; P <= 16; P++) {
+        for (int P = 1; P <= LAM_HIP_MAX_SHARDS; P++) {
             if ((uint64_t)P > n) continue;
             uint64_t next = 0;
             for (int q = 0; q < P; q++) {
@@ -64,20 +64,20 @@ static int run_plan()
     const uint64_t sizes[] = {1, 2, 3, 7, 8, 9, 63, 64, 77, 255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025, 1536, 2047, 2048, 2050, 3000, 4097};
     for (uint64_t vec : {2ull, 4ull, 8ull})
         for (uint64_t n : sizes)
-            for (int shards : {1, 2, 3, 4, 5, 8, 16}) {
+            for (int shards : {1, 2, 3, 4, 5, 8, 16, 33, 64}) {
                 if ((uint64_t)shards > n) continue;
                 uint64_t bp = 1, bi = 1, nt = 0;
-                const int rc = lam::symv_plan_check(n, shards, vec, 16, &bp, &bi, &nt);
+                const int rc = lam::symv_plan_check(n, shards, vec, LAM_HIP_MAX_SHARDS, &bp, &bi, &nt);
                 CHECK(rc == 0 && bp == 0 && bi == 0 && nt > 0, "plan n=%" PRIu64 " shards=%d vec=%" PRIu64 ": rc %d, %" PRIu64 " bad pairs, %" PRIu64 " bad interior, %" PRIu64 " tasks",
                       n, shards, vec, rc, bp, bi, nt);
             }
     for (auto ns : {std::pair<uint64_t, int>{6144, 1}, {6144, 8}, {5000, 6}, {8190, 7}}) {
         uint64_t bp = 1, bi = 1, nt = 0;
-        CHECK(lam::symv_plan_check(ns.first, ns.second, 2, 16, &bp, &bi, &nt) == 0 && bp == 0 && bi == 0, "plan n=%" PRIu64 " shards=%d", ns.first, ns.second);
+        CHECK(lam::symv_plan_check(ns.first, ns.second, 2, LAM_HIP_MAX_SHARDS, &bp, &bi, &nt) == 0 && bp == 0 && bi == 0, "plan n=%" PRIu64 " shards=%d", ns.first, ns.second);
     }
     uint64_t a, b, c;
-    CHECK(lam::symv_plan_check(0, 1, 2, 16, &a, &b, &c) == -1 && lam::symv_plan_check(10, 11, 2, 16, &a, &b, &c) == -1 &&
-          lam::symv_plan_check(10, 1, 3, 16, &a, &b, &c) == -1 && lam::symv_plan_check(10, 17, 2, 16, &a, &b, &c) == -1, "bad arguments are refused");
+    CHECK(lam::symv_plan_check(0, 1, 2, LAM_HIP_MAX_SHARDS, &a, &b, &c) == -1 && lam::symv_plan_check(10, 11, 2, LAM_HIP_MAX_SHARDS, &a, &b, &c) == -1 &&
+          lam::symv_plan_check(10, 1, 3, LAM_HIP_MAX_SHARDS, &a, &b, &c) == -1 && lam::symv_plan_check(100, LAM_HIP_MAX_SHARDS + 1, 2, LAM_HIP_MAX_SHARDS, &a, &b, &c) == -1, "bad arguments are refused");
     return g_fail;
 }
 
@@ -132,7 +132,7 @@ static void loaders_for_type(const std::string &tmp, const char *tname)
             if (f) fclose(f);
             CHECK(memcmp(x.data(), b.data(), n * sizeof(T)) == 0, "solution payload");
         }
-        for (int P : {2, 3, 7, 16}) {
+        for (int P : {2, 3, 7, 16, 64}) {
             if ((uint64_t)P > n) continue;
             {
                 LAM::ConjugateGradient_MultiGPUS_HIP<T> cg(std::vector<int>(P, 0));

@@ -43,7 +43,7 @@
 
 namespace
 {
-constexpr int kMaxRanks = 16;
+constexpr int kMaxRanks = 64;
 constexpr int kRing = 4;
 constexpr size_t kSlotBytes = 1u << 20;        // one rank's contribution to one collective
 constexpr int kThreads = 256;

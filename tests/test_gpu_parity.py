@@ -938,7 +938,9 @@ def test_symmetric_option_from_the_environment_checks_itself(lam, monkeypatch, c
                                                  # the reference's uneven partition (remainder on the last shard), odd N, fp32 records with an odd length
                                                  ("F64", 1001, 3), ("F64", 5000, 6), ("F32", 1001, 3), ("F64", 4099, 5), ("BF16", 3001, 4),
                                                  # the headline configuration of the option: BASELINE configs[2]'s matrix on 8 row shards
-                                                 ("F64", 65536, 8)])
+                                                 ("F64", 65536, 8),
+                                                 # beyond 16 shards (LAM_HIP_MAX_SHARDS = 64)
+                                                 ("F64", 4099, 33), ("F32", 8192, 64)])
 def test_symmetric_product_on_several_shards(lam, dtype_name, n, shards):
     """Option "symmetric" with several row shards in one process (gather-Ap exchange): every row takes the cyclic window of
     (N-1)/2 columns behind its diagonal (for even N the antipode goes to the upper half's rows), so every pair {i, j} is read
@@ -1049,7 +1051,9 @@ def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
                                                   # the reference's uneven partition (n / P rows each, the remainder on the LAST shard,
                                                   # gathered with MPI_Allgatherv, CPU_MPI_OMP.hpp:176-196,505): records of the longest slice
                                                   (3, 1001, "F64"), (3, 4098, "F64"), (6, 5000, "F64"), (5, 1001, "F64"), (7, 1000, "F32"),
-                                                  (3, 1001, "F32"), (16, 1039, "F64")])
+                                                  (3, 1001, "F32"), (16, 1039, "F64"),
+                                                  # beyond 16 shards (LAM_HIP_MAX_SHARDS = 64 since round 5: the reference's largest run has 64 ranks)
+                                                  (33, 1039, "F64"), (64, 4100, "F64"), (64, 64, "F64")])
 def test_one_process_gather_ap_exchange(lam, oracle, shards, n, dtype_name):
     """One process, several shards, option exchange = 1 (gather-Ap): every shard's GEMV stores its Ap slice and its p.Ap
     partial straight into every shard's gather buffer, ONE join per iteration (through shard 0's stream, or all-to-all
