@@ -4,7 +4,7 @@ shards, seed, exchange) the solve with default options against the solve with a 
 that only change HOW an iteration is launched and enqueued, and with the solve cut into random cg_iterate chunks.
 Product library: fuse_update, gemv_timing, exchange_join.  Tuning build (LAM_HIP_LIB=.../liblam_hip_tuning.so) adds
 the experiments that live there: finalize, host_threads, exchange_hub, persistent / persist_chunk.
-    usage: fuzz_options.py [cases] [seed]"""
+    usage: fuzz_options.py [cases] [seed] [many]      many: 9 ... 64 shards per case instead of 1 ... 5"""
 import importlib
 import os
 import random
@@ -36,12 +36,13 @@ def main():
         TUNING = s0.get_option("tuning_variants") == 1      # noqa: N806
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    many = len(sys.argv) > 3 and sys.argv[3] == "many"
     # LAM_HIP_DIRECT_SAME_DEVICE=1 (+ GPU_MAX_HW_QUEUES >= 2 x shards) in the environment: multi-shard cases also try exchange 2
     direct = os.environ.get("LAM_HIP_DIRECT_SAME_DEVICE", "0") not in ("", "0")
     bad = 0
     for case in range(cases):
         dt, dname = rng.choice(((lam.F64, "f64"), (lam.F64, "f64"), (lam.F32, "f32"), (lam.BF16, "bf16")))
-        shards = rng.choice((1, 1, 1, 2, 3, 5))
+        shards = rng.randint(9, 64) if many else rng.choice((1, 1, 1, 2, 3, 5))
         n = rng.choice((rng.randint(shards * 2, 300), rng.randint(300, 9000), rng.choice((256, 1024, 4096, 4098, 8192, 10000))))
         n = max(n, shards)
         total = min(rng.randint(1, 60), max(1, n // 3))      # stay short of exact convergence (r = 0 gives 0/0, as in the reference)
