@@ -651,6 +651,35 @@ def test_full_size_gemv_is_exact_on_integer_data(lam, dtype_name, n, shards, sym
         assert s.get_option("symmetric_effective") == (1 if symmetric and shards == 1 else 0)
 
 
+def test_maximum_size_symmetric_product_matches_general(lam):
+    """The symmetric product at the largest size a device holds (N=180000 fp64, 259 GB: 704 strips x 88-row-run classes, task and
+    partial offsets at their largest): on a dense random SPD matrix it returns the general GEMV's vector to rounding, and a few CG
+    iterations on it land on the general path's residual."""
+    n = 180000
+    with lam.Solver(lam.F64) as s:
+        try:
+            s.generate_random_spd(n, 99, 1e3)
+        except lam.LamHipError as e:
+            if e.code == -5:
+                pytest.skip("less than 259 GB of free HBM on this device")
+            raise
+        s.generate_random_rhs(100)
+        assert s.check_symmetry() == 0.0
+        x = np.random.default_rng(5).uniform(-1, 1, n)
+        y_gen = s.gemv(x)
+        s.solve(6, 1e-30)
+        err_gen, x_gen = s.stats["rel_err"], s.solution()
+        s.set_option("symmetric", 2)
+        assert s.get_option("symmetric_effective") == 1 and "symv" in s.gemv_kernel_name()
+        y_sym = s.gemv(x)
+        s.solve(6, 1e-30)
+        err_sym, x_sym, st = s.stats["rel_err"], s.solution(), s.stats
+    scale = np.max(np.abs(y_gen))
+    assert np.max(np.abs(y_sym - y_gen)) <= 1e-12 * scale
+    assert abs(err_sym / err_gen - 1) < 1e-9 and np.linalg.norm(x_sym - x_gen) <= 1e-10 * np.linalg.norm(x_gen)
+    assert st["gemv_bytes"] / st["t_gemv"] > 5.0e12       # the general GEMV's bytes per product: the symmetric one reads half of them
+
+
 @pytest.mark.parametrize("dtype_name", ["F32", "BF16"])
 def test_config4_full_size_properties(lam, dtype_name):
     """BASELINE configs[3]: N=131072 (fp32: 68.7 GB, bf16 storage: 34.4 GB; N^2 = 1.7e10 elements, so
