@@ -148,14 +148,15 @@ struct SpinGuard {
     }
 };
 
-struct Finalize {
-    int active;                       // 0: no in-kernel reduction (the launch has no reducer workgroup)
+struct Finalize {                     // (the pointer list comes LAST here and in GemvArgs: the scalars keep their kernarg offsets
+    int active;                       //  whatever kMaxShards is)
+                                      // 0: no in-kernel reduction (the launch has no reducer workgroup)
     int mail;                         // 1: dst.p[j] is a MailSlot of rank j's mailbox (direct exchange, see Mail)
-    PtrList dst;
     int slot;
     unsigned long long seq;           // mail: the iteration tag
     int *host_err;                    // pinned host error word of the bounded waits (may be null): an expired wait is an
                                       // error the caller sees (lam_hip_cg_iterate), never a silent NaN
+    PtrList dst;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -451,11 +452,11 @@ struct GemvArgs {
     uint64_t seg_end[2];
     int nseg;
     int accumulate;         // y[row] += ... instead of y[row] = ...
+    int n_ypeer;
     Finalize fin;           // in-kernel reduction of `partial` by the last workgroup (several shards)
     // gather-Ap exchange with several shards in one process: y[row] also goes, as a peer store over xGMI, to the same
     // row of this shard's record in every OTHER shard's gather buffer (n_ypeer = 0 everywhere else)
     TV *ypeer[kMaxShards - 1];
-    int n_ypeer;
 };
 
 // the row's result: the shard's own copy and the peers' (see GemvArgs::ypeer)
