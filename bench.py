@@ -33,6 +33,10 @@ collective(s) / event join(s), lam_hip_stats.t_exchange) next to `gemv_ms`: gemv
 (ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:352-377).  The headline is always the product's DEFAULT exchange of its topology (the
 other modes are recorded under "exchange_modes" only), and every line checks itself: true == recursive residual, and for N > 1
 the residual of the one-GPU solve of the same system; a failed check prints "value": null with the reason and exits non-zero.
+N > 1: the process's OWN topology runs in a worker thread under a supervisor (the main thread: --headline-timeout, SIGTERM from a
+launcher that is tearing the job down).  If it raises, hangs or is torn down, rank 0 still prints ONE line: the headline it had
+already measured (when only the comparison modes behind it failed: "comparison_error"), or else the OTHER topology's leg record as
+the headline ("headline_from", "own_topology_error"), or -- with no usable leg -- "value": null with the reason; exit code 4.
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (its name comes from the
 library): achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
@@ -43,6 +47,7 @@ own CPU driver (oracle/_ref, built from /root/reference in the build container) 
 binary is missing, the oracle port -- on a bounded sample.
 """
 import argparse
+import copy
 import importlib
 import json
 import os
@@ -50,6 +55,7 @@ import signal
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -436,6 +442,71 @@ def write_leg_record(path, rec):
 # ---------------------------------------------------------------------------------------------------------------------
 # the two multi-GPU topologies
 # ---------------------------------------------------------------------------------------------------------------------
+def maybe_fail_main(leg_name, where):
+    """Test hook (tests/test_gpu_rank_mock.py): LAM_BENCH_FAIL_MAIN=<raise|hang>[:<start|late>] makes the process's OWN topology
+    (not a leg) raise or hang at its start or behind its headline measurement (in the comparison modes)."""
+    spec = os.environ.get("LAM_BENCH_FAIL_MAIN", "")
+    if not spec or leg_name is not None:
+        return
+    how, _, at = spec.partition(":")
+    if (at or "start") != where:
+        return
+    sys.stderr.write(f"[bench] own topology: '{how}' at '{where}' (LAM_BENCH_FAIL_MAIN)\n")
+    if how == "hang":
+        time.sleep(3600)
+    raise RuntimeError(f"LAM_BENCH_FAIL_MAIN={spec}")
+
+
+class Supervised:
+    """Runs fn(on_headline) in a worker thread; the calling (main) thread waits for it, for `timeout` seconds or for SIGTERM.
+    on_headline(rec) is what fn calls once its headline measurement is complete (what follows it only adds comparison modes)."""
+
+    def __init__(self, fn, timeout):
+        self.box = {}
+        self.terminated = False
+        self.timeout = timeout
+
+        def work():
+            try:
+                self.box["rec"] = fn(lambda rec: self.box.__setitem__("headline", rec))
+            except BaseException as e:   # noqa: BLE001
+                self.box["err"] = f"{type(e).__name__}: {e}"[:600]
+
+        self.thread = threading.Thread(target=work, daemon=True, name="own-topology")
+
+    def run(self):
+        old = None
+        try:
+            old = signal.signal(signal.SIGTERM, lambda *_: setattr(self, "terminated", True))
+        except ValueError:       # not the main thread (never in this script)
+            pass
+        t0 = time.time()
+        self.thread.start()
+        while self.thread.is_alive() and time.time() - t0 < self.timeout and not self.terminated:
+            self.thread.join(0.2)
+        if old is not None and not self.terminated:
+            signal.signal(signal.SIGTERM, old)
+        if "rec" in self.box:
+            return self.box["rec"], None
+        err = self.box.get("err") or ("torn down by SIGTERM (the launcher lost another rank?)" if self.terminated
+                                      else f"no result within {self.timeout:.0f} s (--headline-timeout)")
+        return None, err
+
+
+def record_from_leg(leg, steps):
+    """The other topology's leg record (as public() wrote it) in the shape the measure functions return: the fallback headline."""
+    st = {"t_gemv": leg["gemv_ms"] * 1e-3, "t_exchange": leg.get("exchange_us", 0.0) * 1e-6, "gemv_bytes": leg["gemv_bytes_per_launch"],
+          "rel_err": leg["rel_residual_recursive"], "t_comm_init": leg.get("rccl_init_s") or 0.0}
+    if "exchange_us_min_over_ranks" in leg:
+        st["t_exchange_min"] = leg["exchange_us_min_over_ranks"] * 1e-6
+    return {"st": st, "dt": leg["ms_per_step"] * 1e-3 * steps, "true_res": leg["rel_residual_true"], "self_check": leg.get("self_check"),
+            "failures": [leg["error"]] if leg.get("error") else [], "kernel": leg.get("kernel"), "cold_start": None,
+            "parallelism": leg.get("parallelism"), "host_enqueue_us_per_step": leg.get("host_enqueue_us_per_step"),
+            "exchange_effective": leg.get("exchange_effective"), "exchange_modes": leg.get("exchange_modes"),
+            "device_ids": leg.get("device_ids"), "rccl_version": leg.get("rccl_version"), "rccl_ranks": leg.get("rccl_ranks"),
+            "rccl_calls_enqueued": leg.get("rccl_calls_enqueued")}
+
+
 def mode_record(steps, dt_, st_, res_, **extra):
     rec = {"value": steps / dt_, "ms_per_step": dt_ / steps * 1e3, "gemv_ms": st_["t_gemv"] * 1e3, "exchange_us": st_["t_exchange"] * 1e6,
            "gemv_plus_comm_ms": (st_["t_gemv"] + st_["t_exchange"]) * 1e3,
@@ -486,11 +557,12 @@ def self_check(lam, args, n_gpus, st, true_res, rank, rdzv, symmetric=False):
     return check, failures
 
 
-def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
+def rank_mode_measure(lam, args, rdzv, part, leg_name=None, on_headline=None):
     """One process per GPU (this process is one rank; RCCL inside liblam_hip.so).  part = "main": the default exchange (the
     headline of this topology) + the other product exchanges + the symmetric option; part = "direct": the EXPERIMENTAL direct
     exchange only (runs in a leg of its own).  Returns this rank's record (rank 0's is the one that counts)."""
     rank, world = rdzv.rank, rdzv.size
+    maybe_fail_main(leg_name, "start")
     uid = rdzv.broadcast(lam.get_unique_id() if rank == 0 else b"")
     ndev = lam.device_count()          # counting devices does not initialise the GPU
     barrier = rdzv.barrier
@@ -527,6 +599,12 @@ def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
             rec.update(dt=dt, st=st, true_res=true_res, self_check=check, failures=failures, rccl_init_s=st.get("t_comm_init", 0.0))
             default_label = RANK_LABELS.get(default_exchange, str(default_exchange))
             modes = {"default": default_label, default_label: mode_record(args.steps, dt, st, true_res)}
+            # the headline is complete: whatever fails behind this point costs comparison modes, not the line (see Supervised)
+            rec["exchange_modes"] = modes
+            rec["rccl_calls_enqueued"] = s.get_option("collectives_enqueued")
+            if on_headline is not None:
+                on_headline(copy.deepcopy(rec))
+            maybe_fail_main(leg_name, "late")
 
             def timed(label, **opts):
                 for k_, v_ in opts.items():
@@ -626,12 +704,13 @@ def rank_mode_measure(lam, args, rdzv, part, leg_name=None):
         s.close()
 
 
-def one_process_measure(lam, args, n_gpus, part, leg_name=None):
+def one_process_measure(lam, args, n_gpus, part, leg_name=None, on_headline=None):
     """ONE process driving all shards (the reference's ConjugateGradient_MultiGPUS_CUDA topology).  part = "main": the default
     exchange (gather-Ap) + every other product exchange of this topology + the symmetric option, each with the residual check
     against the one-GPU solve and the host time it takes to enqueue an iteration; part = "direct": the EXPERIMENTAL in-kernel flag
     exchange only."""
     n = args.n
+    maybe_fail_main(leg_name, "start")
     # LAM_BENCH_DEVICE_IDS="0,0" (tests on a one-GPU box): put the shards of the one-process topology on these devices
     dev_override = [int(x) for x in os.environ.get("LAM_BENCH_DEVICE_IDS", "").split(",") if x.strip() != ""]
     ndev = max(1, lam.device_count())
@@ -673,6 +752,10 @@ def one_process_measure(lam, args, n_gpus, part, leg_name=None):
                      eff_label: mode_record(args.steps, dt, st, true_res, host_enqueue_us_per_step=host_us, vs_one_gpu=vs_ref(st["rel_err"]),
                                             gemv_ms_fastest_shard=gemv_fastest)}
             rec["exchange_modes"] = modes
+            # the headline is complete: whatever fails behind this point costs comparison modes, not the line (see Supervised)
+            if on_headline is not None:
+                on_headline(copy.deepcopy(rec))
+            maybe_fail_main(leg_name, "late")
             timed_local = make_timed_local(s, args, modes, vs_ref)
             timed_local(LOCAL_LABELS[1] + ", join through shard 0", exchange=1, exchange_join=1)
             timed_local(LOCAL_LABELS[1] + ", all-to-all join", exchange=1, exchange_join=0)
@@ -759,6 +842,7 @@ def public(rec):
         st, dt = rec["st"], rec["dt"]
         steps = rec.get("steps")
         out.update(mode_record(steps, dt, st, rec["true_res"]) if steps else {})
+        out["gemv_bytes_per_launch"] = st.get("gemv_bytes")
         if rec.get("failures"):
             out["error"] = "; ".join(rec["failures"])
             out["value_unchecked"], out["value"] = out.get("value"), None
@@ -855,6 +939,8 @@ def main():
                     "no extrapolation; the reference driver needs 8*N^2 bytes of host memory)")
     ap.add_argument("--cpu-sample-iters", type=int, default=20)
     ap.add_argument("--leg-timeout", type=float, default=120.0, help="seconds a child-process leg may take (a healthy one needs 10-40 s at N=65536)")
+    ap.add_argument("--headline-timeout", type=float, default=240.0, help="N > 1: seconds this process's own topology may take before rank 0 "
+                    "prints the line without it (a healthy one needs 20-60 s at N=65536)")
     ap.add_argument("--mfma-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--leg-out", default=None, help=argparse.SUPPRESS)
@@ -940,21 +1026,45 @@ def main():
 
     # ---- this process's own topology ------------------------------------------------------------------------------------
     exchange_modes, effective_exchange, rccl_info, shard_devices, device_state = None, None, None, None, None
-    if use_dist:
-        rec = rank_mode_measure(lam, args, rdzv, "main")
+    headline_from, own_error, comparison_error = None, None, None
+    if use_dist or n_gpus > 1:
+        # in a worker thread under a supervisor: an exception, a hang or a tear-down by the launcher must not cost rank 0 its line
+        def own(on_headline):
+            if use_dist:
+                return rank_mode_measure(lam, args, rdzv, "main", on_headline=on_headline)
+            return one_process_measure(lam, args, n_gpus, "main", on_headline=on_headline)
+        sup = Supervised(own, args.headline_timeout)
+        rec, err = sup.run()
+        if rec is None and "headline" in sup.box:
+            rec, comparison_error = sup.box["headline"], err       # the headline itself had been measured
+            sys.stderr.write(f"[bench] the comparison modes behind the headline failed: {err}\n")
+        elif rec is None:
+            own_error = err
+            sys.stderr.write(f"[bench] this process's own topology failed: {err}\n")
+            if rank != 0:
+                time.sleep(1.5)          # rank 0 prints first (a launcher tears everything down at the first non-zero exit)
+                os._exit(4)
+            leg = legs.get("one_process" if use_dist else "rank_mode") or {}
+            if isinstance(leg.get("gemv_ms"), (int, float)) and isinstance(leg.get("ms_per_step"), (int, float)) and leg.get("gemv_bytes_per_launch"):
+                rec = record_from_leg(leg, args.steps)
+                headline_from = ("the one-process topology's leg" if use_dist else "the rank mode's leg (RCCL)") + " -- this process's own topology failed"
+            else:
+                out = {"metric": "cg_iterations_per_sec", "value": None, "unit": "iterations/s", "n_gpus": n_gpus, "steps": args.steps,
+                       "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                       "data": "synthetic", "config": {"workload": f"dense SPD CG, N={n} fp64 (BASELINE configs[2])", "n": n},
+                       "error": f"own topology failed: {err}; no usable leg of the other topology: {leg.get('error', 'not run')}"[:900]}
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+                os._exit(4)
         st, dt, true_res, check, failures = rec["st"], rec["dt"], rec["true_res"], rec["self_check"], rec["failures"]
         kernel_name, cold_start, parallelism = rec["kernel"], rec["cold_start"], rec["parallelism"]
         host_us_per_step, effective_exchange = rec["host_enqueue_us_per_step"], rec["exchange_effective"]
-        exchange_modes = rec["exchange_modes"] if world > 1 or forced_rccl else None
-        rccl_info = {"rccl_version": rec["rccl_version"], "rccl_ranks": rec["rccl_ranks"], "rccl_calls_enqueued_rank0": rec["rccl_calls_enqueued"]}
-        s = None
-    elif n_gpus > 1:
-        rec = one_process_measure(lam, args, n_gpus, "main")
-        st, dt, true_res, check, failures = rec["st"], rec["dt"], rec["true_res"], rec["self_check"], rec["failures"]
-        kernel_name, cold_start, parallelism = rec["kernel"], rec["cold_start"], rec["parallelism"]
-        host_us_per_step, effective_exchange = rec["host_enqueue_us_per_step"], rec["exchange_effective"]
-        exchange_modes = rec["exchange_modes"]
-        shard_devices = rec["device_ids"]
+        from_rank_mode = use_dist != (headline_from is not None)          # which topology the headline record describes
+        if from_rank_mode:
+            exchange_modes = rec["exchange_modes"] if world > 1 or forced_rccl or headline_from else None
+            rccl_info = {"rccl_version": rec["rccl_version"], "rccl_ranks": rec["rccl_ranks"], "rccl_calls_enqueued_rank0": rec["rccl_calls_enqueued"]}
+        else:
+            exchange_modes = rec["exchange_modes"]
+            shard_devices = rec["device_ids"]
         s = None
     else:
         s = lam.Solver(lam.F64)
@@ -977,7 +1087,7 @@ def main():
 
     # (the experimental legs are merged into the exchange modes of the topology they belong to: merge_direct)
     other_topology = None
-    if rank == 0 and (n_gpus > 1 or forced_rccl):
+    if rank == 0 and (n_gpus > 1 or forced_rccl) and headline_from is None:
         if use_dist:
             merge_direct(exchange_modes, legs.get("rank_direct"), true_res)
             other_topology = legs.get("one_process")
@@ -988,6 +1098,10 @@ def main():
             other_topology = legs.get("rank_mode")
             if other_topology is not None:
                 merge_direct(other_topology.setdefault("exchange_modes", {}), legs.get("rank_direct"), other_topology.get("rel_residual_true"))
+    elif rank == 0 and headline_from is not None:
+        # the headline IS the other topology's leg: its experimental leg goes with it; the failed topology is reported as such
+        merge_direct(exchange_modes, legs.get("one_direct" if use_dist else "rank_direct"), true_res)
+        other_topology = {"error": own_error}
 
     # Side measurements, same process, same context, AFTER the headline (N=1 only, not under a profiler):
     # the opt-in symmetric product on the same system, then configs[1] (N=32768) and the sizes the reference
@@ -1131,9 +1245,14 @@ def main():
         **({"device_state": device_state} if device_state else {}),
     }
     if n_gpus > 1 and rank == 0:
-        # the topology this process is not, measured by child processes in front of the headline (None: legs were switched off)
-        key = "one_process_topology" if use_dist else "rank_mode_rccl"
+        # the topology the headline is not: measured by child processes in front of the headline (None: legs were switched off) --
+        # or, when the headline had to come from that leg, this process's own topology with the reason it failed
+        key = "one_process_topology" if use_dist != (headline_from is not None) else "rank_mode_rccl"
         out[key] = other_topology if other_topology is not None else ({"skipped": "--no-legs, a profiler, or --symmetric"} if not want_legs else {"error": "leg not run"})
+    if headline_from is not None:
+        out["headline_from"], out["own_topology_error"] = headline_from, own_error
+    if comparison_error is not None:
+        out["comparison_error"] = comparison_error
 
     if also:
         out["also"] = also
@@ -1157,6 +1276,10 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if own_error is not None or comparison_error is not None:
+        # the worker thread may still sit in a native call (and the other ranks may be gone): no barrier, no destructors
+        sys.stderr.write(f"[bench] line printed without a complete run of this process's own topology: {own_error or comparison_error}\n")
+        os._exit(4)
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()

@@ -73,3 +73,46 @@ def test_merge_of_an_experimental_leg_into_its_topology():
     assert modes["a"]["value"] == 100.0                                      # the headline's record is untouched
     bench.merge_direct(None, {"error": "x"}, 0.5)                            # no modes (one GPU) / no leg: nothing to do
     bench.merge_direct(modes, None, 0.5)
+
+
+def test_supervised_own_topology_and_the_fallback_record():
+    """N > 1: the process's own topology runs in a worker thread; the supervisor hands back its record, or -- when it raises,
+    hangs past the timeout or the launcher sends SIGTERM -- the reason, with whatever headline the worker had already published."""
+    import signal
+    import threading
+    rec, err = bench.Supervised(lambda pub: {"value": 3.0}, 5.0).run()
+    assert rec == {"value": 3.0} and err is None
+
+    def raises(pub):
+        raise RuntimeError("no peer access")
+    sup = bench.Supervised(raises, 5.0)
+    rec, err = sup.run()
+    assert rec is None and err == "RuntimeError: no peer access" and "headline" not in sup.box
+
+    def hangs_late(pub):
+        pub({"value": 7.0})
+        time.sleep(30)
+    sup = bench.Supervised(hangs_late, 1.0)
+    t0 = time.time()
+    rec, err = sup.run()
+    assert rec is None and "--headline-timeout" in err and sup.box["headline"] == {"value": 7.0} and time.time() - t0 < 5
+
+    sup = bench.Supervised(lambda pub: time.sleep(30), 20.0)
+    threading.Timer(0.5, lambda: os.kill(os.getpid(), signal.SIGTERM)).start()
+    t0 = time.time()
+    rec, err = sup.run()
+    assert rec is None and "SIGTERM" in err and time.time() - t0 < 5
+    signal.signal(signal.SIGTERM, signal.SIG_DFL)
+
+    # the other topology's leg record (what public() writes) as the fallback headline: same arithmetic as a measured one
+    st = {"t_gemv": 0.6e-3, "t_exchange": 20e-6, "t_exchange_min": 12e-6, "gemv_bytes": 4.3e9, "rel_err": 1e-3, "t_comm_init": 2.5}
+    leg = bench.public({"st": st, "dt": 0.013, "true_res": 1.0000001e-3, "steps": 20, "failures": [], "kernel": "k", "parallelism": "p", "self_check": {"passed": True},
+                        "exchange_effective": 1, "host_enqueue_us_per_step": 9.0, "exchange_modes": {"default": "x"}, "rccl_ranks": 8, "rccl_version": "2.x",
+                        "rccl_calls_enqueued": 99, "rccl_init_s": 2.5, "n_gpus": 8})
+    assert leg["gemv_bytes_per_launch"] == 4.3e9
+    back = bench.record_from_leg(leg, 20)
+    assert abs(back["dt"] - 0.013) < 1e-12 and back["failures"] == [] and back["true_res"] == 1.0000001e-3 and back["rccl_ranks"] == 8
+    for k in ("t_gemv", "t_exchange", "t_exchange_min", "gemv_bytes", "rel_err", "t_comm_init"):
+        assert abs(back["st"][k] - st[k]) <= 1e-12 * abs(st[k]), k
+    bad = bench.record_from_leg(dict(leg, error="process 3 exited with signal 9"), 20)
+    assert bad["failures"] == ["process 3 exited with signal 9"]

@@ -532,3 +532,53 @@ def test_bench_headline_survives_a_dying_leg(mock_async, tmp_path, victim):
     else:
         assert "error" in rm and "value" not in rm, rm
         assert len([m for m in modes.values() if m.get("value", 0) > 0]) == 6
+
+
+@pytest.mark.parametrize("how,expect_from", [("raise", "leg"), ("hang", "leg"), ("raise:late", "own"), ("hang:late", "own")])
+def test_bench_line_survives_its_own_topology(mock_async, tmp_path, how, expect_from):
+    """`python bench.py --gpus 2`: the process's OWN topology runs in a worker thread under a supervisor.  The test hook
+    (LAM_BENCH_FAIL_MAIN) makes it raise or hang before anything is measured -- the line's headline then comes from the OTHER
+    topology's leg (the rank mode on the RCCL double, measured by child processes beforehand), named as such -- or behind its
+    headline measurement, in the comparison modes -- the headline is its own, with "comparison_error".  Exit code 4 either way:
+    the run was not complete, the line says why."""
+    gpus = 2
+    env = _one_process_env(mock_async, gpus, LAM_BENCH_FAIL_MAIN=how, LAM_BENCH_DIRECT="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "3", "--order", "8192",
+                        "--leg-timeout", "90", "--headline-timeout", "25"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 4, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == gpus and out["value"] > 0 and out["self_check"]["passed"], out
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 1) < 1e-9
+    rf = out["roofline"]
+    assert 0 < rf["frac"] < 1 and abs(rf["algorithmic_bytes_per_launch"] - (8.0 * 8192 * 8192 / gpus + 8.0 * (8192 + 8192 / gpus))) < 1
+    if expect_from == "leg":
+        assert "rank mode" in out["headline_from"] and "1 process/GPU" in out["config"]["parallelism"], out
+        assert ("LAM_BENCH_FAIL_MAIN" if how == "raise" else "--headline-timeout") in out["own_topology_error"]
+        assert out["host_plumbing"]["rccl_ranks"] == gpus and out["exchange_modes"]["default"] == "allgather_Ap"
+        assert abs(out["value"] / out["exchange_modes"]["allgather_Ap"]["value"] - 1) < 1e-12      # rebuilt from the leg's ms_per_step
+        assert out["one_process_topology"] == {"error": out["own_topology_error"]} and "rank_mode_rccl" not in out
+    else:
+        assert "headline_from" not in out and "1 process" in out["config"]["parallelism"]
+        assert ("LAM_BENCH_FAIL_MAIN" if how.startswith("raise") else "--headline-timeout") in out["comparison_error"]
+        assert out["exchange_modes"]["default"].startswith("gather_Ap") and out["rank_mode_rccl"]["value"] > 0
+
+
+@pytest.mark.parametrize("how", ["raise", "raise:late"])
+def test_bench_torchrun_line_survives_the_rank_mode(mock_mp_lib, tmp_path, how):
+    """The driver's torchrun command with the rank mode (the headline of that launch style) failing on every rank: rank 0 still
+    prints ONE line -- from the one-process topology's leg when nothing had been measured, its own headline when only the
+    comparison modes failed -- before the launcher tears the job down."""
+    r = _bench_torchrun(mock_mp_lib, 2, tmp_path, extra_env={"LAM_BENCH_FAIL_MAIN": how, "LAM_BENCH_DIRECT": "0"})
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["self_check"]["passed"], out
+    if how == "raise":
+        assert "one-process" in out["headline_from"] and "1 process," in out["config"]["parallelism"] and "LAM_BENCH_FAIL_MAIN" in out["own_topology_error"]
+        assert out["rank_mode_rccl"] == {"error": out["own_topology_error"]} and out["exchange_modes"]["default"].startswith("gather_Ap")
+    else:
+        assert "headline_from" not in out and "LAM_BENCH_FAIL_MAIN" in out["comparison_error"] and out["host_plumbing"]["rccl_ranks"] == 2
+        assert out["one_process_topology"]["value"] > 0
