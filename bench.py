@@ -451,6 +451,9 @@ def maybe_fail_main(leg_name, where):
     how, _, at = spec.partition(":")
     if (at or "start") != where:
         return
+    only = os.environ.get("LAM_BENCH_FAIL_MAIN_RANK", "")        # under a launcher: only this rank fails
+    if only != "" and only != os.environ.get("RANK", "0"):
+        return
     sys.stderr.write(f"[bench] own topology: '{how}' at '{where}' (LAM_BENCH_FAIL_MAIN)\n")
     if how == "hang":
         time.sleep(3600)

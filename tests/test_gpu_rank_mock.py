@@ -582,3 +582,17 @@ def test_bench_torchrun_line_survives_the_rank_mode(mock_mp_lib, tmp_path, how):
     else:
         assert "headline_from" not in out and "LAM_BENCH_FAIL_MAIN" in out["comparison_error"] and out["host_plumbing"]["rccl_ranks"] == 2
         assert out["one_process_topology"]["value"] > 0
+
+
+def test_bench_torchrun_line_survives_a_tear_down(mock_mp_lib, tmp_path):
+    """One rank of the rank mode dies at its start while rank 0 waits for it: the launcher tears the job down with SIGTERM, rank 0's
+    supervisor (its main thread, never inside a native call; SIGTERM itself: tests/test_bench_cpu.py) prints the line from the
+    one-process topology's leg before it goes."""
+    r = _bench_torchrun(mock_mp_lib, 2, tmp_path, extra_env={"LAM_BENCH_FAIL_MAIN": "raise", "LAM_BENCH_FAIL_MAIN_RANK": "1", "LAM_BENCH_DIRECT": "0"})
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["self_check"]["passed"], out
+    # (what rank 0 notices first: the launcher's SIGTERM, or its rendezvous connection to the dead rank closing)
+    assert "one-process" in out["headline_from"] and ("SIGTERM" in out["own_topology_error"] or "rendezvous peer" in out["own_topology_error"]), out
