@@ -774,7 +774,7 @@ def test_randomised_many_shards(lam, oracle):
     shard), every storage type, both exchanges, the general and the symmetric product; the partition is the reference's, the
     GEMV and a few CG iterations agree with the fp64 oracle on the matrix the device holds."""
     rng = np.random.default_rng(6464)
-    for case in range(36):
+    for case in range(16):
         P = int(rng.integers(9, 65))
         n = int(rng.choice([P, P + int(rng.integers(0, P)), int(rng.integers(P, 600)), int(rng.integers(600, 2600))]))
         dt_name = ["F64", "F64", "F32", "BF16"][int(rng.integers(0, 4))]
@@ -1123,7 +1123,7 @@ def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
                                                   (3, 1001, "F64"), (3, 4098, "F64"), (6, 5000, "F64"), (5, 1001, "F64"), (7, 1000, "F32"),
                                                   (3, 1001, "F32"), (16, 1039, "F64"),
                                                   # beyond 16 shards (LAM_HIP_MAX_SHARDS = 64 since round 5: the reference's largest run has 64 ranks)
-                                                  (33, 1039, "F64"), (64, 4100, "F64"), (64, 64, "F64")])
+                                                  (33, 1039, "F64"), (64, 4100, "F64"), pytest.param(64, 64, "F64", marks=pytest.mark.slow)])
 def test_one_process_gather_ap_exchange(lam, oracle, shards, n, dtype_name):
     """One process, several shards, option exchange = 1 (gather-Ap): every shard's GEMV stores its Ap slice and its p.Ap
     partial straight into every shard's gather buffer, ONE join per iteration (through shard 0's stream, or all-to-all

@@ -20,7 +20,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, slow
 
 pytestmark = pytest.mark.gpu
 MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
@@ -83,16 +83,16 @@ def _check_solution(out, P, n, mode):
 
 
 @pytest.mark.parametrize("P,n,mode,overlap,exchange", [
-    (2, 1024, "tridiag", 1, 0),     # even split, aligned panels
+    slow(2, 1024, "tridiag", 1, 0),     # even split, aligned panels
     (3, 1001, "tridiag", 1, 0),     # odd N: generic kernel; uneven split: grouped broadcasts
-    (4, 4096, "spd", 1, 0),
+    slow(4, 4096, "spd", 1, 0),
     (4, 4096, "spd", 0, 0),         # all-gather on the compute stream
-    (3, 4098, "spd", 1, 0),         # 1366 rows per rank
+    slow(3, 4098, "spd", 1, 0),         # 1366 rows per rank
     (4, 4102, "spd", 1, 0),         # remainder on the last rank, odd row offsets -> no panel split
     (8, 8192, "spd", 1, 0),         # the node shape
     # exchange = 1: ONE all-gather of [Ap slice | p.Ap partial] per iteration, full-length r and p per rank
-    (2, 1024, "tridiag", 1, 1),
-    (4, 4096, "spd", 1, 1),
+    slow(2, 1024, "tridiag", 1, 1),
+    slow(4, 4096, "spd", 1, 1),
     (8, 8192, "spd", 1, 1),
     (3, 1001, "tridiag", 1, 1),     # uneven split (the reference's: remainder on the last rank): records of the longest slice
     (3, 4098, "spd", 1, 1),
@@ -101,12 +101,12 @@ def _check_solution(out, P, n, mode):
     (24, 4100, "spd", 1, 1),        # beyond 16 ranks (LAM_HIP_MAX_SHARDS = 64 since round 5), uneven split; exchange 0 passes too
                                     # but takes 97 s: its three collectives per iteration time-slice 24 queues of one GPU
     # exchange = 2: direct stores into peer-mapped mailboxes and p replicas, no collective in the iteration
-    (2, 1024, "tridiag", 1, 2),
-    (4, 4096, "spd", 1, 2),
+    slow(2, 1024, "tridiag", 1, 2),
+    slow(4, 4096, "spd", 1, 2),
     (8, 8192, "spd", 1, 2),
     (3, 1001, "tridiag", 1, 2),     # odd N (generic kernel), uneven split
     (4, 4102, "spd", 1, 2),         # odd row offsets: the GEMV is not split
-    (4, 4096, "spd", 0, 2),         # overlap 0: flag wait first, then ONE GEMV launch
+    slow(4, 4096, "spd", 0, 2),         # overlap 0: flag wait first, then ONE GEMV launch
     (8, 8192, "spd", 0, 2),
 ])
 def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, overlap, exchange):
@@ -128,7 +128,7 @@ def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, ov
         assert out["collectives_enqueued"][0] < 40 + 4 * P, out
 
 
-@pytest.mark.parametrize("P,n", [(2, 1024), (4, 4096), (8, 8192), (3, 1001), (6, 5000)])
+@pytest.mark.parametrize("P,n", [slow(2, 1024), slow(4, 4096), (8, 8192), (3, 1001), (6, 5000)])
 def test_one_process_gather_ap_is_bit_identical_to_rank_mode_gather_ap(mock_async, tmp_path, P, n):
     """exchange 1 exists in both multi-GPU topologies: one process per GPU (ONE ncclAllGather of [Ap slice | p.Ap partial]
     per iteration) and one process driving all shards (the GEMV stores the records into the peers' buffers itself, one
@@ -156,7 +156,7 @@ def test_one_process_gather_ap_is_bit_identical_to_rank_mode_gather_ap(mock_asyn
         assert got == (out["iters"], out["rel_err"], out["x_sha"]), (join, got, out)
 
 
-@pytest.mark.parametrize("P,n", [(2, 1024), (4, 4096), (8, 8192), (3, 3000), (3, 1001), (6, 5000)])
+@pytest.mark.parametrize("P,n", [slow(2, 1024), slow(4, 4096), (8, 8192), slow(3, 3000), (3, 1001), (6, 5000)])
 def test_symmetric_product_rank_mode_matches_one_process(mock_async, tmp_path, P, n):
     """Option "symmetric" in rank mode (one process per GPU; here threads on the stream-ordered RCCL double): the iteration's one
     collective gathers every rank's full-length contribution to A p.  Same kernels and the same summation order as one process
@@ -180,7 +180,7 @@ def test_symmetric_product_rank_mode_matches_one_process(mock_async, tmp_path, P
     assert got == (out["iters"], out["rel_err"], out["x_sha"]), (got, out)
 
 
-@pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), (4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
+@pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), slow(4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
 def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path, P, n, mode):
     """exchange 2 sums the ranks' partial dot products with the same reduction tree as exchange 0, so the
     two must produce the same bits: iteration count, residual and every element of x -- in all four launch shapes
@@ -203,26 +203,26 @@ def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path,
 
 @pytest.mark.parametrize("P,n,mode,exchange,delay,chunk", [
     # GPU outruns the host (small N: an iteration takes a few microseconds), run to convergence
-    (2, 1024, "tridiag", 0, "", 0),
+    slow(2, 1024, "tridiag", 0, "", 0),
     (4, 2048, "tridiag", 0, "", 0),
-    (8, 4096, "spd", 0, "", 0),
-    (4, 2048, "tridiag", 1, "", 0),
+    slow(8, 4096, "spd", 0, "", 0),
+    slow(4, 2048, "tridiag", 1, "", 0),
     (8, 4096, "spd", 1, "", 0),
     # one rank's host lags far behind its GPU (it sleeps before every enqueue) while the others run ahead
-    (2, 1024, "tridiag", 0, "1:150", 0),
-    (4, 2048, "spd", 0, "2:200", 0),
+    slow(2, 1024, "tridiag", 0, "1:150", 0),
+    slow(4, 2048, "spd", 0, "2:200", 0),
     (4, 2048, "spd", 1, "0:200", 0),
     (8, 4096, "spd", 0, "3:100,6:250", 0),
     # the host outruns the GPU (four 2 GB shards on one GPU: an iteration takes more than a millisecond)
-    (4, 32768, "spd", 0, "", 0),
+    slow(4, 32768, "spd", 0, "", 0),
     (4, 32768, "spd", 1, "", 0),
     # the solve split over several lam_hip_cg_iterate calls: the stop must also be agreed on across calls
     (4, 2048, "tridiag", 0, "1:100", 7),
-    (2, 1024, "tridiag", 1, "", 5),
+    slow(2, 1024, "tridiag", 1, "", 5),
     # the direct exchange under the same stresses
-    (4, 2048, "tridiag", 2, "", 0),
+    slow(4, 2048, "tridiag", 2, "", 0),
     (8, 4096, "spd", 2, "3:100,6:250", 0),
-    (4, 32768, "spd", 2, "", 0),
+    slow(4, 32768, "spd", 2, "", 0),
     (4, 2048, "tridiag", 2, "1:100", 7),
 ])
 def test_stop_protocol_keeps_ranks_in_step(mock_async, tmp_path, P, n, mode, exchange, delay, chunk):
@@ -377,7 +377,7 @@ def _check_bench_line(r, nproc):
     return out
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
+@pytest.mark.parametrize("nproc", [2, slow(4)])
 def test_bench_torchrun_path_end_to_end_on_mock_rccl(mock_mp_lib, tmp_path, nproc):
     """The exact command line the driver uses for N > 1 GPUs -- torch.distributed.run, one process per
     rank, the package's own rendezvous (no torch in the workers), unique-id broadcast, both exchange modes,
@@ -534,7 +534,7 @@ def test_bench_headline_survives_a_dying_leg(mock_async, tmp_path, victim):
         assert len([m for m in modes.values() if m.get("value", 0) > 0]) == 6
 
 
-@pytest.mark.parametrize("how,expect_from", [("raise", "leg"), ("hang", "leg"), ("raise:late", "own"), ("hang:late", "own")])
+@pytest.mark.parametrize("how,expect_from", [("raise", "leg"), ("hang", "leg"), ("raise:late", "own"), slow("hang:late", "own")])
 def test_bench_line_survives_its_own_topology(mock_async, tmp_path, how, expect_from):
     """`python bench.py --gpus 2`: the process's OWN topology runs in a worker thread under a supervisor.  The test hook
     (LAM_BENCH_FAIL_MAIN) makes it raise or hang before anything is measured -- the line's headline then comes from the OTHER
@@ -544,7 +544,7 @@ def test_bench_line_survives_its_own_topology(mock_async, tmp_path, how, expect_
     gpus = 2
     env = _one_process_env(mock_async, gpus, LAM_BENCH_FAIL_MAIN=how, LAM_BENCH_DIRECT="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "3", "--order", "8192",
-                        "--leg-timeout", "90", "--headline-timeout", "25"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--leg-timeout", "90", "--headline-timeout", "8"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 4, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]

@@ -69,11 +69,13 @@ def run_point(exe, args, timeout=900):
     return r.returncode, line, r.stderr, time.time() - t0
 
 
-def gen_grid(exe, sol, out):
+def gen_grid(exe, sol, out, sizes=None, extra=True):
     gold = json.load(open(GOLD))
     ok = True
-    for e in gold["entries"] + gold.get("entries_extra", []):      # extra: `-s 80000 -i 1000` of the GPU weak-scaling series
+    for e in gold["entries"] + (gold.get("entries_extra", []) if extra else []):      # extra: `-s 80000 -i 1000` of the GPU weak-scaling series
         n = e["n"]
+        if sizes and n not in sizes:
+            continue
         fits = 8.0 * n * n + 64.0 * n < 0.97 * HBM_BYTES
         prec = "f64" if fits else "f32"
         rc, line, err, wall = run_point(exe, ["-s", str(n), "-i", str(e["max_iters"]), "-o", sol, "-t", prec])
@@ -213,12 +215,14 @@ def main():
     ap.add_argument("--files", help="directory for real matrix/rhs files (file grid)")
     ap.add_argument("--files-max-n", type=int, default=30000)
     ap.add_argument("--file-sizes", default=",".join(str(x) for x in FILE_GRID))
+    ap.add_argument("--gen-sizes", default="", help="gen grid: only these sizes (default: every published one)")
+    ap.add_argument("--no-gen-extra", action="store_true", help="gen grid: skip the 1000-iteration point of the weak-scaling series")
     a = ap.parse_args()
     sol = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lam_sweep_sol_{os.getpid()}.bin")
     out, ok = [], True
     print("# " + COLUMNS, flush=True)
     if a.grid in ("gen", "all"):
-        ok &= gen_grid(a.exe, sol, out)
+        ok &= gen_grid(a.exe, sol, out, [int(x) for x in a.gen_sizes.split(",") if x], not a.no_gen_extra)
     if a.grid in ("file", "all"):
         ok &= file_grid(a.exe, sol, out, a.files, a.files_max_n, [int(x) for x in a.file_sizes.split(",") if x])
     scaling = [g for g in ("strong", "weak") if a.grid in (g, "scaling")]
