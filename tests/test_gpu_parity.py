@@ -704,11 +704,11 @@ def test_config4_full_size_properties(lam, dtype_name):
 
 
 # ------------------------------------------------------------------------------------------------
-# randomised sweep over sizes, shard counts and dtypes (seeded: the same 40 cases every run)
+# randomised sweep over sizes, shard counts and dtypes (seeded: the same 28 cases every run)
 # ------------------------------------------------------------------------------------------------
 def test_randomised_sizes_and_shards(lam, oracle):
     rng = np.random.default_rng(2024)
-    for case in range(40):
+    for case in range(28):
         n = int(rng.integers(1, 1500))
         P = int(rng.integers(1, min(n, 6) + 1))
         dt_name = ["F64", "F64", "F32", "BF16"][int(rng.integers(0, 4))]
@@ -741,7 +741,7 @@ def test_randomised_sizes_and_shards_symmetric(lam, oracle):
     antipode rule --; ragged last strips and last tasks), 1 ... 6 row shards (the gather-Ap exchange; every other case with the
     reference's uneven partition), every storage type; a few iterations against the fp64 oracle on the matrix the device holds."""
     rng = np.random.default_rng(4202)
-    for case in range(40):
+    for case in range(28):
         P = int(rng.integers(1, 7))
         n = P * int(rng.integers(1, 1500 // P + 1))
         if case % 2 == 1:
@@ -774,7 +774,7 @@ def test_randomised_many_shards(lam, oracle):
     shard), every storage type, both exchanges, the general and the symmetric product; the partition is the reference's, the
     GEMV and a few CG iterations agree with the fp64 oracle on the matrix the device holds."""
     rng = np.random.default_rng(6464)
-    for case in range(16):
+    for case in range(12):
         P = int(rng.integers(9, 65))
         n = int(rng.choice([P, P + int(rng.integers(0, P)), int(rng.integers(P, 600)), int(rng.integers(600, 2600))]))
         dt_name = ["F64", "F64", "F32", "BF16"][int(rng.integers(0, 4))]
@@ -1123,7 +1123,7 @@ def test_host_enqueue_variants_are_bit_identical(lam, shards, n):
                                                   (3, 1001, "F64"), (3, 4098, "F64"), (6, 5000, "F64"), (5, 1001, "F64"), (7, 1000, "F32"),
                                                   (3, 1001, "F32"), (16, 1039, "F64"),
                                                   # beyond 16 shards (LAM_HIP_MAX_SHARDS = 64 since round 5: the reference's largest run has 64 ranks)
-                                                  (33, 1039, "F64"), (64, 4100, "F64"), pytest.param(64, 64, "F64", marks=pytest.mark.slow)])
+                                                  (33, 1039, "F64"), pytest.param(64, 4100, "F64", marks=pytest.mark.slow), pytest.param(64, 64, "F64", marks=pytest.mark.slow)])   # (64: test_randomised_many_shards)
 def test_one_process_gather_ap_exchange(lam, oracle, shards, n, dtype_name):
     """One process, several shards, option exchange = 1 (gather-Ap): every shard's GEMV stores its Ap slice and its p.Ap
     partial straight into every shard's gather buffer, ONE join per iteration (through shard 0's stream, or all-to-all
@@ -1428,6 +1428,6 @@ def test_fuzz_bit_preserving_options(lam, build):
     env = dict(os.environ)
     if build == "tuning":
         env["LAM_HIP_LIB"] = lam.TUNING_LIB
-    cases = "120" if build == "product" else "80"
+    cases = "80" if build == "product" else "50"       # (1000 + 1000 cases once per round: profiles/r05_fuzz_summary.txt)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_options.py"), cases, "11"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and f"{cases} of {cases} cases" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

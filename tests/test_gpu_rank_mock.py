@@ -86,7 +86,7 @@ def _check_solution(out, P, n, mode):
     slow(2, 1024, "tridiag", 1, 0),     # even split, aligned panels
     (3, 1001, "tridiag", 1, 0),     # odd N: generic kernel; uneven split: grouped broadcasts
     slow(4, 4096, "spd", 1, 0),
-    (4, 4096, "spd", 0, 0),         # all-gather on the compute stream
+    slow(4, 4096, "spd", 0, 0),         # all-gather on the compute stream
     slow(3, 4098, "spd", 1, 0),         # 1366 rows per rank
     (4, 4102, "spd", 1, 0),         # remainder on the last rank, odd row offsets -> no panel split
     (8, 8192, "spd", 1, 0),         # the node shape
@@ -105,9 +105,9 @@ def _check_solution(out, P, n, mode):
     slow(4, 4096, "spd", 1, 2),
     (8, 8192, "spd", 1, 2),
     (3, 1001, "tridiag", 1, 2),     # odd N (generic kernel), uneven split
-    (4, 4102, "spd", 1, 2),         # odd row offsets: the GEMV is not split
+    slow(4, 4102, "spd", 1, 2),         # odd row offsets: the GEMV is not split
     slow(4, 4096, "spd", 0, 2),         # overlap 0: flag wait first, then ONE GEMV launch
-    (8, 8192, "spd", 0, 2),
+    slow(8, 8192, "spd", 0, 2),
 ])
 def test_rank_mode_multi_rank_on_async_mock(mock_async, tmp_path, P, n, mode, overlap, exchange):
     r, out, lines = _run(mock_async, tmp_path, P, n, mode, "--overlap", overlap, "--exchange", exchange)
@@ -180,7 +180,7 @@ def test_symmetric_product_rank_mode_matches_one_process(mock_async, tmp_path, P
     assert got == (out["iters"], out["rel_err"], out["x_sha"]), (got, out)
 
 
-@pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), slow(4, 4096, "spd"), (8, 8192, "spd"), (3, 4098, "spd")])
+@pytest.mark.parametrize("P,n,mode", [(2, 1024, "tridiag"), slow(4, 4096, "spd"), slow(8, 8192, "spd"), (3, 4098, "spd")])
 def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path, P, n, mode):
     """exchange 2 sums the ranks' partial dot products with the same reduction tree as exchange 0, so the
     two must produce the same bits: iteration count, residual and every element of x -- in all four launch shapes
@@ -211,7 +211,7 @@ def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path,
     # one rank's host lags far behind its GPU (it sleeps before every enqueue) while the others run ahead
     slow(2, 1024, "tridiag", 0, "1:150", 0),
     slow(4, 2048, "spd", 0, "2:200", 0),
-    (4, 2048, "spd", 1, "0:200", 0),
+    slow(4, 2048, "spd", 1, "0:200", 0),
     (8, 4096, "spd", 0, "3:100,6:250", 0),
     # the host outruns the GPU (four 2 GB shards on one GPU: an iteration takes more than a millisecond)
     slow(4, 32768, "spd", 0, "", 0),
@@ -223,7 +223,7 @@ def test_direct_exchange_is_bit_identical_to_rccl_exchange(mock_async, tmp_path,
     slow(4, 2048, "tridiag", 2, "", 0),
     (8, 4096, "spd", 2, "3:100,6:250", 0),
     slow(4, 32768, "spd", 2, "", 0),
-    (4, 2048, "tridiag", 2, "1:100", 7),
+    slow(4, 2048, "tridiag", 2, "1:100", 7),
 ])
 def test_stop_protocol_keeps_ranks_in_step(mock_async, tmp_path, P, n, mode, exchange, delay, chunk):
     """Convergence under asynchronous collectives: all ranks must enqueue the same number of collectives
@@ -386,7 +386,7 @@ def test_bench_torchrun_path_end_to_end_on_mock_rccl(mock_mp_lib, tmp_path, npro
     _check_bench_line(_bench_torchrun(mock_mp_lib, nproc, tmp_path), nproc)
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
+@pytest.mark.parametrize("nproc", [2, slow(4)])
 def test_bench_torchrun_path_on_async_mock_across_processes(mock_async, tmp_path, nproc):
     """Same command on the stream-ordered mock with the ranks in SEPARATE processes (slot ring shared
     through HIP IPC): the process-per-GPU shape of the real deployment under asynchronous collectives."""
