@@ -36,7 +36,7 @@ the residual of the one-GPU solve of the same system; a failed check prints "val
 N > 1: the process's OWN topology runs in a worker thread under a supervisor (the main thread: --headline-timeout, SIGTERM from a
 launcher that is tearing the job down).  If it raises, hangs or is torn down, rank 0 still prints ONE line: the headline it had
 already measured (when only the comparison modes behind it failed: "comparison_error"), or else the OTHER topology's leg record as
-the headline ("headline_from", "own_topology_error"), or -- with no usable leg -- "value": null with the reason; exit code 4.
+the headline ("headline_from", "own_topology_error"; exit code 4), or -- with no usable leg -- "value": null with the reason (4).
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (its name comes from the
 library): achieved = algorithmic bytes of one launch / its average duration measured with HIP events on
@@ -1282,7 +1282,7 @@ def main():
     if own_error is not None or comparison_error is not None:
         # the worker thread may still sit in a native call (and the other ranks may be gone): no barrier, no destructors
         sys.stderr.write(f"[bench] line printed without a complete run of this process's own topology: {own_error or comparison_error}\n")
-        os._exit(4)
+        os._exit(4 if own_error is not None else 0)       # comparison modes only: the headline is complete and checked
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()
