@@ -283,8 +283,12 @@ class Solver:
         self._chk(self._L.lam_hip_generate_tridiag(self._h))
         return True
 
-    def generate_random_spd(self, n, seed, cond):
-        self.set_problem(n)
+    def generate_random_spd(self, n, seed, cond, keep_problem=False):
+        """keep_problem: a context that already holds a problem of this size keeps its allocations (no lam_hip_set_problem: its
+        hipFree waits for the whole device, which deadlocks rank contexts that are THREADS of one process -- the test harness's
+        shape -- as soon as another rank has a collective in flight that waits for this one)."""
+        if not (keep_problem and getattr(self, "n", None) == n):
+            self.set_problem(n)
         self._chk(self._L.lam_hip_generate_random_spd(self._h, seed, cond))
 
     def generate_spectrum_spd(self, eig, reflectors):

@@ -126,7 +126,10 @@ const char *lam_hip_last_error(const lam_hip_ctx *ctx); /* ctx may be NULL: last
  * shard; on the device every row is padded to a whole number of 4-KiB pages -- an internal layout, upload / download take and
  * give dense rows -- so that any N, odd ones included, streams through the aligned 16-byte-vector kernels) and the work vectors.  Stands in for the allocation half of load_matrix_from_file /
  * generate_matrix (ConjugateGradient_CPU_MPI_OMP.hpp:176-196,214,250-253;
- * ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:544-568). */
+ * ConjugateGradient_MultiGPUS_CUDA_NCCL.cu:544-568).  Frees the previous problem's vectors first: hipFree waits for the
+ * whole device AS THIS PROCESS sees it, so a process that hosts several rank contexts as threads (the test harness's shape;
+ * a deployment has one rank per process) must not call it while another of its ranks has a collective in flight that waits
+ * for this one.  A new matrix of the SAME size needs no new lam_hip_set_problem. */
 int lam_hip_set_problem(lam_hip_ctx *ctx, uint64_t n);
 
 /* The row partition itself, usable without a context (and without a GPU): rows of shard q of P for

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -185,6 +186,8 @@ struct Comm {
     unsigned long long seq = 0;
     int *host_abort = nullptr;           // pinned, written by this rank's kernels
     long delay_us = 0;
+    struct Call { unsigned long long seq; unsigned op; size_t count, bytes; int root; void *stream; };
+    std::vector<Call> trace;             // MOCK_RCCL_TRACE_DIR
 };
 
 std::mutex g_mu;
@@ -232,6 +235,10 @@ ncclResult_t enqueue(Comm *c, unsigned op, const void *send, void *recv, size_t 
         return ncclInternalError;
     }
     if (c->delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(c->delay_us));
+    // MOCK_RCCL_TRACE_DIR=<dir>: every call is noted in memory and written to <dir>/rank<r>.txt when the communicator goes (to find
+    // where the ranks' call sequences part; a file write per call would change the timing the question is about)
+    static const bool tracing = getenv("MOCK_RCCL_TRACE_DIR") != nullptr;
+    if (tracing) c->trace.push_back({c->seq, op, count, bytes, root, (void *)stream});
     hipLaunchKernelGGL(collective_kernel, dim3(1), dim3(kThreads), 0, stream, c->w->ctrl, c->w->slots, (volatile int *)c->host_abort,
                        c->rank, c->w->nranks, c->seq, op, send, recv, bytes, (unsigned long long)count, root, timeout_ticks());
     c->seq++;
@@ -342,6 +349,15 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     Ctrl h;
     memset(&h, 0, sizeof h);
     (void)hipMemcpy(&h, c->w->ctrl, sizeof h, hipMemcpyDeviceToHost);
+    if (const char *dir = getenv("MOCK_RCCL_TRACE_DIR")) {
+        char path[512];
+        snprintf(path, sizeof path, "%s/rank%d.txt", dir, c->rank);
+        if (FILE *f = fopen(path, "a")) {
+            fprintf(f, "# communicator of %d ranks, %llu calls, err %u (rank %u, peer %u, call %llu)\n", c->w->nranks, c->seq, h.err, h.err_rank, h.err_peer, h.err_seq);
+            for (const auto &t : c->trace) fprintf(f, "%llu op %u count %zu bytes %zu root %d stream %p\n", t.seq, t.op, t.count, t.bytes, t.root, t.stream);
+            fclose(f);
+        }
+    }
     if (const char *path = getenv("MOCK_RCCL_STATS_FILE")) {
         char line[512];
         const int n = snprintf(line, sizeof line,

@@ -323,6 +323,17 @@ def test_direct_exchange_context_can_be_destroyed_right_after_iterating(mock_asy
         os.remove(os.path.join(str(tmp_path), "mock_stats.jsonl"))
 
 
+def test_repeated_solves_on_live_rank_contexts(mock_async, tmp_path):
+    """tests/mock_rccl/soak_ranks.py, short form (the long one: profiles/r05_soak.txt, 5100 solves): every rank context solves
+    twelve systems to convergence one after the other WITHOUT being recreated -- the three exchanges and both overlap settings
+    in rotation, the stop agreed on by all ranks every time --; all ranks hold the same bits, every pass repeats the first
+    pass's bits, the direct exchange gives the bits of exchange 0, nothing falls back."""
+    for P, n, rounds in ((4, 4096, 36), (3, 1001, 36)):
+        env, stats = _env(mock_async, P, tmp_path)
+        r = subprocess.run([sys.executable, os.path.join(MOCK_DIR, "soak_ranks.py"), str(P), str(n), str(rounds)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and f"{rounds} solves per rank to convergence" in r.stdout and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---- multi-process: the driver's exact torchrun command ------------------------------------------------
 def _bench_torchrun(mock, nproc, tmp_path, extra_env=None):
     # LAM_BENCH_DEVICE_IDS / LAM_HIP_DIRECT_SAME_DEVICE: rank 0's one-process legs put all their shards on GPU 0 too
