@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on ONE box: alternating child processes, each timing the GEMV alone (lam_hip_gemv_only) and a
-short CG run.     usage: ab_libs.py libA.so libB.so [rounds]"""
+short CG run.     usage: ab_libs.py libA.so libB.so [libC.so ...] [rounds]"""
 import json
 import os
 import subprocess
@@ -8,11 +8,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
-import importlib, json, sys
+import importlib, json, os, sys
 sys.path.insert(0, %r)
 lam = importlib.import_module("2024-eumaster4hpc-student-challenge_amd")
 out = {}
-for name, dt, n in (("f64", lam.F64, 65536), ("f32", lam.F32, 131072), ("bf16", lam.BF16, 131072), ("f64_40000", lam.F64, 40000)):
+for name, dt, n in [x for x in (("f64", lam.F64, 65536), ("f32", lam.F32, 131072), ("bf16", lam.BF16, 131072), ("f64_40000", lam.F64, 40000)) if not os.environ.get("AB_ONLY") or x[0] in os.environ["AB_ONLY"].split(",")]:
     with lam.Solver(dt) as s:
         s.generate_random_spd(n, 5, 1e3)
         s.generate_random_rhs(6)
@@ -27,8 +27,8 @@ print(json.dumps(out))
 
 
 def main():
-    libs = sys.argv[1:3]
-    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    libs = [a for a in sys.argv[1:] if not a.isdigit()]
+    rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
     for r in range(rounds):
         for lib in libs:
             env = dict(os.environ, LAM_HIP_LIB=os.path.abspath(lib), LAM_HIP_ALLOW_STALE="1")
