@@ -590,6 +590,42 @@ def test_rows_are_padded_to_pages_and_any_n_runs_the_vector_kernels(lam, dtype_n
             assert np.max(np.abs(y_gen - y_ref) / scale) <= (1e-13 if dtype_name == "F64" else 32 * 2.0 ** -24)
 
 
+def test_degenerate_inputs_behave_like_the_reference_loop(lam, oracle):
+    """Inputs the reference's loop (ConjugateGradient_CPU_OMP.hpp:49-91, restated by the oracle) handles without any special case, and
+    so must this path: b = 0 (bb = 0: the stop test is 0/0 = NaN, never true; alpha = 0/0: x turns NaN; max_iters + 1 iterations, not
+    converged), A = I (the residual is exactly 0 after one step), a tolerance every residual meets (stops in iteration 1), max_iters 0
+    and 1 (num_iters = max_iters + 1), 1 x 1 and 2 x 2 systems -- on one shard and on 2 / 3 shards with both exchanges: the same
+    iteration count, the same converged flag, NaN where the reference's arithmetic gives NaN, the same x otherwise."""
+    rng = np.random.default_rng(3)
+    n = 96
+    q, _ = np.linalg.qr(rng.uniform(-1, 1, (n, n)))
+    A = (q * np.exp(rng.uniform(-1, 1, n))) @ q.T
+    A = 0.5 * (A + A.T)
+    b = rng.uniform(-1, 1, n)
+    cases = [("b = 0", A, np.zeros(n), 20, 1e-9), ("A = I", np.eye(n), b, 20, 1e-9), ("tolerance 10", A, b, 20, 10.0),
+             ("max_iters 0", A, b, 0, 1e-9), ("max_iters 1", A, b, 1, 1e-9), ("1 x 1", np.array([[4.0]]), np.array([2.0]), 5, 1e-9),
+             ("2 x 2", np.array([[2.0, 1.0], [1.0, 3.0]]), np.array([1.0, -1.0]), 10, 1e-12)]
+    for name, A_, b_, iters, tol in cases:
+        x_or, st_or = oracle.cg_solve(A_, b_, iters, tol)
+        for shards, exchange in ((1, None), (3, 0), (3, 1), (2, 1)):
+            if shards > A_.shape[0]:
+                continue
+            with lam.Solver(lam.F64, device_ids=[0] * shards) as s:
+                s.set_matrix(A_)
+                s.set_rhs(b_)
+                if exchange is not None:
+                    s.set_option("exchange", exchange)
+                conv = s.solve(iters, tol)
+                x, st = s.solution(), s.stats
+            what = (name, shards, exchange, st, st_or)
+            assert st["num_iters"] == st_or["num_iters"] and bool(conv) == bool(st_or["converged"]), what
+            assert np.array_equal(np.isnan(x), np.isnan(x_or)), what
+            assert np.allclose(np.nan_to_num(x), np.nan_to_num(x_or), rtol=1e-12, atol=1e-300), what
+            e, e_or = st["rel_err"], st_or["rel_err"]
+            # (residuals that are zero up to rounding come out as different multiples of 1e-17 under another summation order)
+            assert (np.isnan(e) and np.isnan(e_or)) or max(abs(e), abs(e_or)) < 1e-14 or abs(e - e_or) <= 1e-9 * abs(e_or), what
+
+
 def test_invalid_sizes_are_rejected(lam):
     with lam.Solver(lam.F64, n_shards=4, device_ids=[0] * 4) as s:
         with pytest.raises(lam.LamHipError) as e:
