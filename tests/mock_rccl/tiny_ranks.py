@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Rank mode at the smallest sizes -- one row per rank, one or a few extra rows on the last rank -- on the stream-ordered RCCL double,
 every exchange, the symmetric product on gather-Ap: ranks identical, the oracle with the same number of ranks, the host-recomputed
-residual.      usage: LD_PRELOAD=tests/mock_rccl/libmock_rccl_async.so python tools/tiny_ranks.py"""
+residual.  (Under tests/: the comparison runs the oracle, which only tests may.)
+    usage: LD_PRELOAD=tests/mock_rccl/libmock_rccl_async.so python tests/mock_rccl/tiny_ranks.py"""
 import json
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RUN = os.path.join(ROOT, "tests", "mock_rccl", "run_ranks.py")
+RUN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "run_ranks.py")
 
 
 def main():

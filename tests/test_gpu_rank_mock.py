@@ -98,7 +98,7 @@ def _check_solution(out, P, n, mode):
     (3, 4098, "spd", 1, 1),
     (6, 5000, "spd", 1, 1),
     (5, 1001, "spd", 1, 1),
-    (4, 5, "spd", 1, 1),            # one row per rank, two on the last (all 36 tiny shapes x exchanges: tools/tiny_ranks.py)
+    (4, 5, "spd", 1, 1),            # one row per rank, two on the last (all 36 tiny shapes x exchanges: tests/mock_rccl/tiny_ranks.py)
     (8, 8, "spd", 1, 0),
     (8, 8, "spd", 1, 2),
     (24, 4100, "spd", 1, 1),        # beyond 16 ranks (LAM_HIP_MAX_SHARDS = 64 since round 5), uneven split; exchange 0 passes too
