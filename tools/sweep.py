@@ -191,7 +191,8 @@ def scaling_grid(exe, sol, out, which, launchers, scale, mpiexec, mpi_exe, prelo
                             "reference_iters": [lo, hi], "match": int(f[1]) == procs and float(f[8]) < 1e-9 and (0.97 if scale >= 1.0 else 0.93) * lo <= it <= 1.03 * hi})
             ok &= rec["match"]
             out.append(rec)
-            rs = f"{e_ref['speedup_iter_vs_p1']}x iter / {e_ref['speedup_cg_vs_p1']}x cg ({e_ref['source']})" if e_ref and "speedup_iter_vs_p1" in e_ref else \
+            rs = (f"{e_ref['speedup_iter_vs_p1']}x iter / " + (f"{e_ref['speedup_cg_vs_p1']}x" if e_ref.get('speedup_cg_vs_p1') is not None else "not published") +
+                  f" cg ({e_ref['source']})") if e_ref and "speedup_iter_vs_p1" in e_ref else \
                  (f"t_iter {e_ref['t_iter']} s ({e_ref['source']})" if e_ref else "no published line")
             print(("ok   " if rec["match"] else "FAIL ") + f"{which:6s} {topo:11s} N={n:6d} P={procs}: {line}"
                   + (f"   speed-up {rec['speedup_iter']:.2f}x iter / {rec['speedup_cg']:.2f}x cg" if rec.get("speedup_iter") else "")
