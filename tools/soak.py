@@ -3,7 +3,7 @@
 list of (dtype, N, shards, exchange, symmetric) configurations, solve the same seeded systems over and over for `seconds` and
 compare every solution's bits with the first pass.  A hand-over that ever delivered a stale value, or a bounded wait that ever
 expired, shows up as a different hash or an error.  Prints a progress line every ~20 s.
-    usage: soak.py [seconds]"""
+    usage: soak.py [seconds] [many]      many: the configurations with 17 ... 64 shards, the symmetric product and fp32 / bf16 among them"""
 import hashlib
 import importlib
 import os
@@ -23,6 +23,12 @@ CONFIGS = [  # dtype, n, shards, exchange, symmetric, iterations per solve
 ]
 
 
+CONFIGS_MANY = [
+    ("F64", 4099, 33, 1, 2, 150), ("F64", 4100, 64, 1, 0, 150), ("F32", 8192, 64, 1, 2, 100), ("F64", 2051, 17, 0, 0, 150), ("BF16", 6000, 24, 1, 2, 80),
+    ("F64", 64, 64, 1, 0, 60), ("F32", 3001, 40, 0, 0, 100), ("F64", 16384, 16, 1, 2, 60),
+]
+
+
 def one(s, cfg, seed):
     dt, n, shards, exchange, sym, iters = cfg
     s.generate_random_spd(n, seed, 1e7)
@@ -38,9 +44,10 @@ def one(s, cfg, seed):
 
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    configs = CONFIGS_MANY if len(sys.argv) > 2 and sys.argv[2] == "many" else CONFIGS
     t0 = time.time()
     ctx, ref, solves, bad = [], {}, 0, 0
-    for cfg in CONFIGS:
+    for cfg in configs:
         dt, n, shards, exchange, sym, iters = cfg
         s = lam.Solver(getattr(lam, dt), device_ids=[0] * shards)
         if exchange is not None:
@@ -51,7 +58,7 @@ def main():
     last = t0
     rnd = 0
     while time.time() - t0 < seconds:
-        for i, (s, cfg) in enumerate(zip(ctx, CONFIGS)):
+        for i, (s, cfg) in enumerate(zip(ctx, configs)):
             for seed in (21, 57):
                 # alternate the launch-chain options that must not change a bit
                 s.set_option("fuse_update", (rnd + i) % 2 if rnd % 3 == 2 else 1)
@@ -68,8 +75,8 @@ def main():
         if time.time() - last > 20:
             last = time.time()
             print(f"# {time.time() - t0:6.0f} s: {rnd} rounds, {solves} solves, {bad} mismatches", flush=True)
-    iters_total = sum(c[5] for c in CONFIGS) * 2 * rnd
-    print(f"# soak: {time.time() - t0:.0f} s, {rnd} rounds x {len(CONFIGS)} configurations x 2 systems = {solves} solves, {iters_total} CG iterations, {bad} mismatches")
+    iters_total = sum(c[5] for c in configs) * 2 * rnd
+    print(f"# soak: {time.time() - t0:.0f} s, {rnd} rounds x {len(configs)} configurations x 2 systems = {solves} solves, {iters_total} CG iterations, {bad} mismatches")
     for s in ctx:
         s.close()
     return 1 if bad else 0
